@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the IF-chain FIR path (BASELINE.json metric) on N MI355X of one node.
+
+A "step" is one pass of the hot path (if_fir_process_device through the C-ABI of libif_fir.so) over one batch of
+device-resident synthetic IQ samples.  Default workload = BASELINE.json configs[2], the configuration the metric is
+quoted on: 255-tap complex-IQ FIR + decimate-by-4 polyphase, one channel of 2^28 samples per GPU.  With --gpus N the
+driver launches one rank per GPU (torch.distributed, backend nccl = RCCL); channels are independent, so ranks share
+no data-path collective and scaling is weak (one channel per GPU).  `--scatter` additionally times the RCCL
+scatter/gather of whole channels from rank 0 (reported in "extra", never in `value`).
+
+Prints ONE JSON line on rank 0.  The oracle (oracle/) is used only for the cpu_baseline leg and a parity spot check.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak, packed FMA counted
+
+WORKLOADS = {
+    # name: (taps, decimation, log2 samples, description)
+    "fir255_dec4_2p28": (255, 4, 28, "255-tap complex-IQ FIR + decimate-by-4 polyphase, one channel per GPU, 2^28 IQ samples (BASELINE configs[2])"),
+    "fir127_2p26": (127, 1, 26, "127-tap complex-IQ FIR, one channel per GPU, 2^26 IQ samples (BASELINE configs[1])"),
+    "fir255_2p28": (255, 1, 28, "255-tap complex-IQ FIR, no decimation, one channel per GPU, 2^28 IQ samples"),
+    "fir255_dec4_2p24": (255, 4, 24, "255-tap + decimate-by-4, 2^24 IQ samples (quick check size)"),
+}
+
+
+def algorithmic_bytes_per_sample(decim):
+    return 8.0 + 8.0 / decim          # read 8 B per input sample, write 8/D
+
+
+def algorithmic_flops_per_sample(taps, decim):
+    return 4.0 * taps / decim         # real taps x complex data: 2 FMA = 4 flop per tap per OUTPUT sample
+
+
+def cpu_baseline(taps_arr, decim, budget_s=12.0):
+    """Time the oracle's float32 OpenMP direct form on the host cores (kind "port": no reference CPU code exists)."""
+    oracle = graft.load_oracle()
+    handle = None
+    try:  # rebuild with -march=native for this host into a temp dir (the shipped .so is x86-64-v3)
+        out = os.path.join(tempfile.mkdtemp(prefix="if_fir_oracle_"), "libif_fir_oracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", out,
+                               os.path.join(ROOT, "oracle", "if_fir_oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        handle = oracle.lib(out)
+    except Exception:
+        handle = None
+    lib = handle or oracle.lib()
+    threads = oracle.max_threads()
+    n = 1 << 24
+    t = taps_arr.size
+    buf = np.zeros(2 * (n + t - 1), dtype=np.float32)      # T-1 zero history in front of the stream (phase 0)
+    buf[2 * (t - 1):] = oracle.synth_iq(n)
+    y = np.empty(2 * ((n + decim - 1) // decim), dtype=np.float32)
+    import ctypes
+    f32p = ctypes.POINTER(ctypes.c_float)
+    args = (taps_arr.ctypes.data_as(f32p), t, decim, buf.ctypes.data_as(f32p), n, y.ctypes.data_as(f32p), threads)
+    lib.oracle_fir_c64_f32_omp(*args)                      # warm-up (page faults, thread pool)
+    best, spent, reps = None, 0.0, 0
+    while spent < budget_s and reps < 64:
+        t0 = time.perf_counter()
+        lib.oracle_fir_c64_f32_omp(*args)
+        dt = time.perf_counter() - t0
+        spent += dt
+        reps += 1
+        best = dt if best is None else min(best, dt)
+    kernel_dt = best
+    return {"value": round(n / kernel_dt / 1e6, 2), "unit": "MSamples/s", "cores": threads, "kind": "port",
+            "sample": "2^24 IQ samples of the same synthetic stream, taps=%d decimation=%d, float32 OpenMP direct form "
+                      "(oracle/if_fir_oracle.c oracle_fir_c64_f32_omp), best of %d runs, %s build; build-authored CPU "
+                      "baseline: the reference has no CPU implementation" %
+                      (taps_arr.size, decim, reps, "-march=native" if handle is not None else "x86-64-v3")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fir255_dec4_2p28", choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (if_fir_set_tuning)")
+    ap.add_argument("--scatter", action="store_true", help="also time RCCL scatter/gather of channels from rank 0")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: libif_fir has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = graft.load_pkg()
+    fir = pkg.if_fir
+    taps_n, decim, log2n, desc = WORKLOADS[args.workload]
+    n = 1 << log2n
+    taps = fir.bpf_design(taps_n)
+    f = fir.IfFir(taps, decim, 0, device=local_rank)
+    if args.variant is not None:
+        f.set_tuning(args.variant)
+    stream = torch.cuda.current_stream()
+    f.set_stream(stream.cuda_stream)     # kernels run on torch's current stream so torch.cuda.Event brackets them
+    m = f.out_count(n)
+    x = torch.empty(2 * n, dtype=torch.float32, device=dev)
+    y = torch.empty(2 * m, dtype=torch.float32, device=dev)
+    channel = rank                      # weak scaling: one independent transponder channel per GPU
+    f.synth_device(x.data_ptr(), 0, n, channel)
+    torch.cuda.synchronize()
+
+    # every step continues the stream (history + phase carried): identical work per step, no reset memset
+    def step_stream():
+        f.process_device(x.data_ptr(), y.data_ptr(), n)
+
+    for _ in range(args.warmup):
+        step_stream()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step_stream()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+    t = torch.tensor([wall, dev_ms_per_step], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max, dev_ms_max = float(t[0].item()), float(t[1].item())
+
+    extra = {}
+    if args.scatter and world > 1:
+        cs = pkg.channel_shard
+        root_inputs = None
+        if rank == 0:
+            root_inputs = [x] + [torch.empty_like(x) for _ in range(world - 1)]
+            for c in range(1, world):
+                f.synth_device(root_inputs[c].data_ptr(), 0, n, c)
+            torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        mine = cs.scatter_channels(root_inputs, world, n, dev, root=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_scatter = time.perf_counter() - ts
+        outs = {}
+        for c, xin in mine.items():
+            yo = torch.empty(2 * f.out_count(n), dtype=torch.float32, device=dev)
+            f.process_device(xin.data_ptr(), yo.data_ptr(), n)
+            outs[c] = yo
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_filter = time.perf_counter() - ts - t_scatter
+        cs.gather_outputs(outs, world, m, dev, root=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_all = time.perf_counter() - ts
+        extra["scatter_gather"] = {"scatter_s": t_scatter, "filter_s": t_filter, "gather_s": t_all - t_scatter - t_filter,
+                                   "end_to_end_msamples_per_s": world * n / t_all / 1e6,
+                                   "note": "RCCL grouped send/recv of whole channels from rank 0 over xGMI"}
+
+    if rank == 0:
+        ms_per_step = wall_max / args.steps * 1e3
+        value = world * n / (wall_max / args.steps) / 1e6
+        bytes_per_launch = algorithmic_bytes_per_sample(decim) * n
+        flops_per_launch = algorithmic_flops_per_sample(taps_n, decim) * n
+        achieved_gbs = bytes_per_launch / (dev_ms_max * 1e-3) / 1e9
+        achieved_tf = flops_per_launch / (dev_ms_max * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        # parity spot check (oracle as checker only): first 4096 outputs of this rank's last step vs the order model.
+        # the stream was continued for warmup+steps calls, so regenerate the expected state cheaply: only check that
+        # a fresh context reproduces the oracle on the head of the stream.
+        oracle = graft.load_oracle()
+        f2 = fir.IfFir(taps, decim, 0, device=local_rank)
+        f2.set_stream(stream.cuda_stream)
+        if args.variant is not None:
+            f2.set_tuning(args.variant)
+        head = 1 << 16
+        yh = torch.empty(2 * f2.out_count(head), dtype=torch.float32, device=dev)
+        f2.process_device(x.data_ptr(), yh.data_ptr(), head)
+        torch.cuda.synchronize()
+        xh = x[:2 * head].cpu().numpy()
+        model = oracle.fir_f32fma(taps, xh, decim, seg_mode=1, seg_len=32)
+        l2, mx = oracle.err_metrics(yh.cpu().numpy(), oracle.fir_f64(taps, xh, decim))
+        parity = {"bit_exact_vs_f32_order_model": bool(np.array_equal(yh.cpu().numpy(), model)),
+                  "rel_l2_vs_f64_oracle": l2, "rel_max_vs_f64_oracle": mx, "window": "first 2^16 input samples"}
+        f2.close()
+        line = {
+            "metric": "complex-IQ MSamples/s through %d-tap FIR" % taps_n,
+            "value": round(value, 1), "unit": "MSamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "name": args.workload, "taps": taps_n, "decimation": decim,
+                       "samples_per_channel": n, "channels_per_gpu": 1,
+                       "parallelism": "channel-parallel x%d, no data-path collective" % world,
+                       "backend": {1: "hip_direct", 2: "hip_tapsplit", 3: "hip_generic", 4: "hip_fft"}[f.get_backend()],
+                       "device": f.device_info()},
+            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms": round(dev_ms_max, 4),
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "HIP events on the launch stream around the timed steps / steps (includes the "
+                                 "~2 us history-update kernel); direct form is co-limited by the FP32 VALU: see valu"},
+            "valu": {"achieved": round(achieved_tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved_tf / VALU_PEAK_TFLOPS, 4)},
+            "parity": parity,
+        }
+        if extra:
+            line["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(taps, decim)
+        print(json.dumps(line), flush=True)
+    f.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

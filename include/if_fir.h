@@ -1,0 +1,116 @@
+/*
+ * if_fir.h — C ABI of libif_fir.so: MI355X-native IF-chain FIR filter / decimator for complex IQ streams.
+ *
+ * Plain C99, no HIP types.  Host code stays C and reaches the CDNA4 kernels through these entry points.
+ *
+ * WHAT THIS REPLACES IN THE REFERENCE: nothing that exists.  vankxr/qo-100-tools has no filter entry
+ * point to bind: `util/if-bandpass-filter/` is an analog LC design
+ * (/root/reference/util/if-bandpass-filter/schematic.svg:174-222) and `software/opi-rf-manager/package.json:6-15`
+ * lists no DSP dependency.  The surface below is BUILD-DEFINED; only the reference's *conventions* are kept:
+ *   - snake_case `module_verb_noun` names and Hungarian argument prefixes
+ *     (/root/reference/software/upconverter/src/main.c:572,585  — `ulSamples`, `pfPData`, `fAttenuation`);
+ *   - `uint8_t` status, 1 = success, 0 = failure
+ *     (/root/reference/software/upconverter/src/f1958.c:12-27, .../src/include/adf4351.h:93-100);
+ *   - small enums for modes (/root/reference/software/gpsdo/src/include/ocxo.h:15-19).
+ *
+ * Semantics: docs/SPEC.md.   y[n] = Σ_k h[k]·x[n-k],  y_D[m] = y[mD],  interleaved float32 I/Q, real float32 taps,
+ * T-1 samples of history and the decimation phase carried across calls.
+ *
+ * Error model: every function that can fail returns 0 and records a message retrievable with
+ * if_fir_last_error(); nothing aborts or throws across the boundary; a context stays usable after a failed call.
+ * There is NO CPU fallback: without a usable HIP device if_fir_init() fails.
+ *
+ * Threading: one context = one HIP stream, not re-entrant; distinct contexts may be used from distinct threads.
+ */
+#ifndef IF_FIR_H
+#define IF_FIR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IF_FIR_VERSION_MAJOR 0
+#define IF_FIR_VERSION_MINOR 1
+
+#define IF_FIR_MAX_TAPS 4096u
+#define IF_FIR_MAX_DECIMATION 64u
+
+typedef struct if_fir_ctx if_fir_ctx_t; /* opaque: device buffers, history, phase, stream, last error */
+
+/* kernel families.  AUTO picks per (T, D). */
+enum
+{
+    IF_FIR_BACKEND_AUTO = 0,
+    IF_FIR_BACKEND_HIP_DIRECT = 1,  /* register-blocked sample-stationary direct form, taps in SGPRs            */
+    IF_FIR_BACKEND_HIP_TAPSPLIT = 2,/* taps staged in LDS, split over 4 lanes, partial sums reduced with DPP     */
+    IF_FIR_BACKEND_HIP_GENERIC = 3, /* any T ≤ 4096, any D ≤ 64 (rolled loops)                                    */
+    IF_FIR_BACKEND_HIP_FFT = 4      /* overlap-save, 4096-point LDS-resident FFT (T ≤ 1025, D = 1)               */
+};
+
+/* window ids for if_bpf_design */
+enum
+{
+    IF_BPF_WINDOW_RECT = 0,
+    IF_BPF_WINDOW_HAMMING = 1,
+    IF_BPF_WINDOW_HANN = 2,
+    IF_BPF_WINDOW_BLACKMAN = 3
+};
+
+/* ---- tap generator (host, once; SPEC §4) ------------------------------------------------------ */
+/* Windowed-sinc band-pass, odd ulTaps, band [dLow,dHigh] in cycles/sample (0 ≤ dLow < dHigh ≤ 0.5),
+ * unity gain at the band centre.  Defaults used by the benchmarks: 0.15–0.25, Blackman. */
+uint8_t if_bpf_design(float *pfTaps, uint32_t ulTaps, double dLow, double dHigh, uint32_t ulWindow);
+
+/* ---- context -------------------------------------------------------------------------------------------------- */
+/* Copies the taps to the device, allocates history (and, for if_fir_process, staging buffers sized for
+ * ullMaxSamples input samples per call).  lDevice = HIP device ordinal. */
+uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t ulTaps, uint32_t ulDecimation,
+                    uint64_t ullMaxSamples, int32_t lDevice);
+void if_fir_destroy(if_fir_ctx_t *pCtx);
+/* zero the history and the decimation phase */
+uint8_t if_fir_reset(if_fir_ctx_t *pCtx);
+uint8_t if_fir_set_backend(if_fir_ctx_t *pCtx, uint32_t ulBackend);
+uint32_t if_fir_get_backend(const if_fir_ctx_t *pCtx); /* the resolved (non-AUTO) backend */
+/* expert knob: pick a tuning variant of the resolved backend's kernel (0 = default).  Also settable
+ * with the environment variable IF_FIR_VARIANT read at if_fir_init. */
+uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant);
+/* run on a caller-owned HIP stream (pass a hipStream_t as void*; NULL = the context's own stream) */
+uint8_t if_fir_set_stream(if_fir_ctx_t *pCtx, void *pStream);
+uint8_t if_fir_synchronize(if_fir_ctx_t *pCtx);
+/* last error message of this context (or of the failed if_fir_init when pCtx is NULL); never NULL */
+const char *if_fir_last_error(const if_fir_ctx_t *pCtx);
+
+/* number of output samples a call with ullSamples inputs will produce in the current phase */
+uint64_t if_fir_out_count(const if_fir_ctx_t *pCtx, uint64_t ullSamples);
+
+/* ---- filtering ------------------------------------------------------------------------------------------------ */
+/* Host pointers: H2D copy + kernel + D2H copy, synchronous.  ullSamples ≤ ullMaxSamples of init. */
+uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float *pfIQOut, uint64_t ullSamples,
+                       uint64_t *pullOutSamples);
+/* Device pointers (16-byte aligned), asynchronous on the context's stream; what the benchmark times.
+ * pDevOut must hold if_fir_out_count() samples. */
+uint8_t if_fir_process_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
+                              uint64_t *pullOutSamples);
+
+/* ---- device-side utilities used by benchmarks and tests ------------------------------------------------------ */
+/* Fill pDevIQ with the SPEC §5 synthetic stream of channel ulChannel, samples [ullFirst, ullFirst+ullSamples). */
+uint8_t if_fir_synth_device(if_fir_ctx_t *pCtx, void *pDevIQ, uint64_t ullFirst, uint64_t ullSamples,
+                            uint32_t ulChannel);
+/* Time ulReps back-to-back if_fir_process_device() calls with HIP events on the context's stream, after
+ * ulWarmup untimed ones; *pfMsPerCall receives the mean.  History/phase are restored afterwards. */
+uint8_t if_fir_time_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
+                           uint32_t ulWarmup, uint32_t ulReps, float *pfMsPerCall);
+/* Device memory helpers so that a pure-C host needs no HIP headers. */
+uint8_t if_fir_dev_alloc(if_fir_ctx_t *pCtx, void **ppDev, uint64_t ullBytes);
+uint8_t if_fir_dev_free(if_fir_ctx_t *pCtx, void *pDev);
+uint8_t if_fir_dev_upload(if_fir_ctx_t *pCtx, void *pDev, const void *pHost, uint64_t ullBytes);
+uint8_t if_fir_dev_download(if_fir_ctx_t *pCtx, void *pHost, const void *pDev, uint64_t ullBytes);
+/* "gfx950", CU count, etc.: writes a short description of the context's device */
+uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOutBytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IF_FIR_H */

@@ -1,0 +1,39 @@
+// if_fir_kernels.h — internal interface between the C-ABI shim and the HIP kernels (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace if_fir
+{
+
+enum
+{
+    BACKEND_AUTO = 0,
+    BACKEND_DIRECT = 1,
+    BACKEND_TAPSPLIT = 2,
+    BACKEND_GENERIC = 3,
+    BACKEND_FFT = 4
+};
+
+struct LaunchArgs
+{
+    const void *in;    // device, interleaved float32 I/Q, N samples
+    void *out;         // device, M samples
+    const float *taps; // device, T floats
+    const void *hist;  // device, T-1 samples (most recent last)
+    int T, D;
+    int64_t N;  // input samples of this call
+    int32_t n0; // offset of the first output sample inside this call's input (0 ≤ n0 < D)
+    int64_t M;  // outputs of this call
+    int backend;
+    int device;
+    hipStream_t stream;
+};
+
+bool direct_supported(int T, int D);
+hipError_t launch_fir(const LaunchArgs &a, int variant);
+hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, hipStream_t stream);
+hipError_t launch_synth(void *iq, uint64_t first, uint64_t count, uint32_t channel, const float *tone10,
+                        hipStream_t stream);
+
+} // namespace if_fir

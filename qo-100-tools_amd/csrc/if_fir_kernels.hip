@@ -1,0 +1,394 @@
+// if_fir_kernels.hip — hand-written CDNA4 (gfx950) kernels of the IF-chain FIR path.
+//
+// BUILD-DEFINED path: the reference vankxr/qo-100-tools holds no filter code
+// (/root/reference/util/if-bandpass-filter/schematic.svg:174-222 is an analog LC drawing), so there is no
+// reference kernel these follow; semantics are docs/SPEC.md, checked against oracle/ by tests/.
+//
+// Direct-form kernel (`fir_direct_kernel`) — "sample-stationary" register blocking:
+//   * a workgroup stages one tile of interleaved I/Q (+ a T-1 halo) from HBM into LDS with coalesced 16-byte loads;
+//   * every lane owns R consecutive (decimated) outputs; it walks the input samples its outputs depend on
+//     ONCE, oldest first, reading two complex samples per ds_read_b128, and applies each sample to all R
+//     accumulators with v_pk_fma_f32 (I and Q in one packed FMA, the tap broadcast from an SGPR via op_sel);
+//   * the loop is fully unrolled over the (compile-time) tap count so every tap index is a constant: taps are
+//     fetched with s_load into SGPRs, edge taps cost nothing, and accumulation segments (SPEC §3) are free of
+//     run-time tests;
+//   * LDS layout: per-lane chunks of D·R samples, each followed by 16 pad bytes, so that the 64 lanes of a
+//     ds_read_b128 (stride D·R·8+16 bytes) fall on distinct bank groups and every address is lane-base + immediate.
+//   * no MFMA: this is a 1-D convolution; the packed-FP32 VALU and HBM are the two rooflines.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "if_fir_kernels.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace if_fir
+{
+
+// --------------------------------------------------------------------------------------------------------------
+// compile-time geometry of one direct-form instantiation
+// --------------------------------------------------------------------------------------------------------------
+template <int T, int D, int R, int BLOCK>
+struct Geo
+{
+    static constexpr int DR = D * R;                               // input samples per lane chunk
+    static constexpr int HALO = ((T - 1 + DR - 1) / DR) * DR;      // halo rounded up to whole chunks
+    static constexpr int TILE_OUT = BLOCK * R;                     // outputs per tile
+    static constexpr int TILE_IN = TILE_OUT * D;                   // new input samples per tile
+    static constexpr int CHUNK_BYTES = DR * 8 + 16;                // padded chunk stride
+    static constexpr int N_CHUNKS = BLOCK + HALO / DR;
+    static constexpr int LDS_IN_BYTES = N_CHUNKS * CHUNK_BYTES;
+    static constexpr int OCHUNK_BYTES = R * 8 + 16;                // padded output chunk (LDS-staged stores)
+    static constexpr int LDS_OUT_BYTES = BLOCK * OCHUNK_BYTES;
+    static constexpr int LDS_BYTES = LDS_IN_BYTES > LDS_OUT_BYTES ? LDS_IN_BYTES : LDS_OUT_BYTES;
+    static_assert(DR % 4 == 0, "chunk must be a multiple of 4 samples (bank-conflict-free padding rule)");
+    static_assert((T - 1) % 2 == 0, "odd tap counts only (pairs of samples are 16-byte aligned in LDS)");
+};
+
+__device__ __forceinline__ f2 fetch_sample(const f2 *__restrict__ in, const f2 *__restrict__ hist, int T, int64_t g,
+                                           int64_t N)
+{
+    if (g >= 0)
+        return (g < N) ? in[g] : (f2){0.f, 0.f};
+    const int64_t h = (int64_t)(T - 1) + g;
+    return (h >= 0) ? hist[h] : (f2){0.f, 0.f};
+}
+
+// one input sample applied to all R accumulators.  C = sample offset relative to the lane's first output sample.
+template <int T, int D, int R, int SEG, int C>
+__device__ __forceinline__ void apply_sample(const f2 s, f2 (&acc)[R], f2 (&tot)[R], const float *__restrict__ taps)
+{
+#pragma unroll
+    for (int r = 0; r < R; r++)
+    {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int k = D * r - C;
+        if (k >= 0 && k < T)
+        {
+            const float h = taps[k];
+            const f2 hh = {h, h};
+            const bool first = (k == T - 1) || (k % SEG == SEG - 1);
+            acc[r] = __builtin_elementwise_fma(s, hh, first ? (f2){0.f, 0.f} : acc[r]);
+            if (k % SEG == 0)
+                tot[r] = (k / SEG == (T - 1) / SEG) ? acc[r] : tot[r] + acc[r];
+        }
+    }
+}
+
+template <int T, int D, int R, int SEG, int C0, int CEND>
+struct Walk
+{
+    // C0 is even relative to -(T-1): one ds_read_b128 = samples C0 and C0+1
+    __device__ static __forceinline__ void run(const char *lane_lds, f2 (&acc)[R], f2 (&tot)[R],
+                                               const float *__restrict__ taps)
+    {
+        using G = Geo<T, D, R, 1>;
+        constexpr int U = C0 + G::HALO;                                   // index inside the lane-relative window
+        constexpr int OFF = (U / G::DR) * G::CHUNK_BYTES + (U % G::DR) * 8; // compile-time LDS byte offset
+        const f4 v = *reinterpret_cast<const f4 *>(lane_lds + OFF);
+        apply_sample<T, D, R, SEG, C0>((f2){v.x, v.y}, acc, tot, taps);
+        if constexpr (C0 + 1 <= CEND)
+            apply_sample<T, D, R, SEG, C0 + 1>((f2){v.z, v.w}, acc, tot, taps);
+        if constexpr (C0 + 2 <= CEND)
+            Walk<T, D, R, SEG, C0 + 2, CEND>::run(lane_lds, acc, tot, taps);
+    }
+};
+
+// --------------------------------------------------------------------------------------------------------------
+// direct-form kernel: one tile per workgroup
+// --------------------------------------------------------------------------------------------------------------
+template <int T, int D, int R, int SEG, int BLOCK, bool LDS_OUT>
+__global__ __launch_bounds__(BLOCK) void fir_direct_kernel(const f2 *__restrict__ in, f2 *__restrict__ out,
+                                                          const float *__restrict__ taps,
+                                                          const f2 *__restrict__ hist, int64_t N, int32_t n0,
+                                                          int64_t M)
+{
+    using G = Geo<T, D, R, BLOCK>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t tile_base = (int64_t)n0 + tile * G::TILE_IN; // stream-relative index of the tile's first output sample
+    const int64_t g0 = tile_base - G::HALO;                   // first sample staged in LDS
+
+    // ---- stage tile + halo into LDS (padded chunk layout) ------------------------------------------------------
+    constexpr int PAIRS = (G::TILE_IN + G::HALO) / 2; // 16-byte units
+    const bool interior = (g0 >= 0) && (g0 + G::TILE_IN + G::HALO <= N) && ((g0 & 1) == 0);
+    if (interior)
+    {
+        const f4 *src = reinterpret_cast<const f4 *>(in + g0);
+#pragma unroll
+        for (int i = 0; i < (PAIRS + BLOCK - 1) / BLOCK; i++)
+        {
+            const int p = tid + i * BLOCK;
+            if ((i + 1) * BLOCK <= PAIRS || p < PAIRS)
+            {
+                const f4 v = src[p];
+                const int u = 2 * p;
+                *reinterpret_cast<f4 *>(smem + (u / G::DR) * G::CHUNK_BYTES + (u % G::DR) * 8) = v;
+            }
+        }
+    }
+    else
+    {
+        for (int p = tid; p < PAIRS; p += BLOCK)
+        {
+            const int u = 2 * p;
+            const f2 a = fetch_sample(in, hist, T, g0 + u, N);
+            const f2 b = fetch_sample(in, hist, T, g0 + u + 1, N);
+            *reinterpret_cast<f4 *>(smem + (u / G::DR) * G::CHUNK_BYTES + (u % G::DR) * 8) = (f4){a.x, a.y, b.x, b.y};
+        }
+    }
+    __syncthreads();
+
+    // ---- compute: walk the samples, oldest first ----------------------------------------------------------------
+    f2 acc[R], tot[R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+    {
+        acc[r] = (f2){0.f, 0.f};
+        tot[r] = (f2){0.f, 0.f};
+    }
+    const char *lane_lds = smem + tid * G::CHUNK_BYTES;
+    Walk<T, D, R, SEG, -(T - 1), D *(R - 1)>::run(lane_lds, acc, tot, taps);
+
+    // ---- store ----------------------------------------------------------------------------------------------------
+    const int64_t m_tile = tile * G::TILE_OUT;
+    if constexpr (LDS_OUT)
+    {
+        __syncthreads(); // everyone is done reading the input tile
+        char *o = smem + tid * G::OCHUNK_BYTES;
+#pragma unroll
+        for (int r = 0; r < R; r += 2)
+            *reinterpret_cast<f4 *>(o + r * 8) = (f4){tot[r].x, tot[r].y, tot[r + 1].x, tot[r + 1].y};
+        __syncthreads();
+        constexpr int OPAIRS = G::TILE_OUT / 2;
+        const bool full = (m_tile + G::TILE_OUT <= M);
+#pragma unroll
+        for (int i = 0; i < OPAIRS / BLOCK; i++)
+        {
+            const int p = tid + i * BLOCK; // pair index inside the tile
+            const int e = 2 * p;           // output index inside the tile
+            const f4 v = *reinterpret_cast<const f4 *>(smem + (e / R) * G::OCHUNK_BYTES + (e % R) * 8);
+            if (full)
+                *reinterpret_cast<f4 *>(out + m_tile + e) = v;
+            else
+            {
+                if (m_tile + e < M)
+                    out[m_tile + e] = (f2){v.x, v.y};
+                if (m_tile + e + 1 < M)
+                    out[m_tile + e + 1] = (f2){v.z, v.w};
+            }
+        }
+    }
+    else
+    {
+        const int64_t m_lane = m_tile + (int64_t)tid * R;
+        if (m_lane + R <= M)
+        {
+#pragma unroll
+            for (int r = 0; r < R; r += 2)
+                *reinterpret_cast<f4 *>(out + m_lane + r) = (f4){tot[r].x, tot[r].y, tot[r + 1].x, tot[r + 1].y};
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (m_lane + r < M)
+                    out[m_lane + r] = tot[r];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// generic kernel: any T ≤ 4096, any D ≤ 64.  One output per thread, taps read through the scalar cache
+// (uniform index), samples straight from global/L2 (neighbouring lanes share lines).  Same summation order
+// as the fast kernels (descending k, segments of SEG).  Correctness fallback, not a performance path.
+// --------------------------------------------------------------------------------------------------------------
+template <int SEG>
+__global__ __launch_bounds__(256) void fir_generic_kernel(const f2 *__restrict__ in, f2 *__restrict__ out,
+                                                         const float *__restrict__ taps,
+                                                         const f2 *__restrict__ hist, int T, int D, int64_t N,
+                                                         int32_t n0, int64_t M)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M)
+        return;
+    const int64_t n = (int64_t)n0 + m * D;
+    f2 acc = {0.f, 0.f}, tot = {0.f, 0.f};
+    const int top = (T - 1) / SEG;
+    for (int k = T - 1; k >= 0; k--)
+    {
+        const float h = taps[k];
+        const f2 s = fetch_sample(in, hist, T, n - k, N);
+        const bool first = (k == T - 1) || (k % SEG == SEG - 1);
+        acc = __builtin_elementwise_fma(s, (f2){h, h}, first ? (f2){0.f, 0.f} : acc);
+        if (k % SEG == 0)
+            tot = (k / SEG == top) ? acc : tot + acc;
+    }
+    out[m] = tot;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// history update: hist_out = last T-1 samples of (hist_in ‖ in)
+// --------------------------------------------------------------------------------------------------------------
+__global__ void fir_history_kernel(const f2 *__restrict__ in, const f2 *__restrict__ hist_in, f2 *__restrict__ hist_out,
+                                   int T, int64_t N)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T - 1)
+        hist_out[i] = fetch_sample(in, hist_in, T, N - (int64_t)(T - 1) + i, N);
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// SPEC §5 synthetic generator (bit-identical to oracle_synth_iq)
+// --------------------------------------------------------------------------------------------------------------
+struct ToneTable
+{
+    float v[10];
+};
+
+__device__ __forceinline__ uint64_t splitmix_mix(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(f2 *__restrict__ iq, uint64_t first, uint64_t count, uint64_t seed,
+                                                   ToneTable tone)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
+    {
+        const uint64_t n = first + i;
+        const uint64_t z = splitmix_mix(seed + (n + 1) * 0x9E3779B97F4A7C15ULL);
+        const float ui = ((float)(uint32_t)(z >> 40) * 0x1p-24f - 0.5f) * 0.5f;
+        const float uq = ((float)(uint32_t)((z >> 16) & 0xFFFFFFu) * 0x1p-24f - 0.5f) * 0.5f;
+        const uint32_t p = (uint32_t)(n % 5u);
+        float ti = tone.v[0], tq = tone.v[1];
+#pragma unroll
+        for (int j = 1; j < 5; j++)
+        {
+            ti = (p == (uint32_t)j) ? tone.v[2 * j] : ti;
+            tq = (p == (uint32_t)j) ? tone.v[2 * j + 1] : tq;
+        }
+        iq[i] = (f2){ti + ui, tq + uq};
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// host-side launchers (called from the C-ABI shim)
+// --------------------------------------------------------------------------------------------------------------
+template <int T, int D, int R, int SEG, int BLOCK, bool LDS_OUT>
+static hipError_t launch_direct(const LaunchArgs &a)
+{
+    using G = Geo<T, D, R, BLOCK>;
+    auto kern = fir_direct_kernel<T, D, R, SEG, BLOCK, LDS_OUT>;
+    static bool attr_done[16] = {false};
+    const int dev = a.device & 15;
+    if (!attr_done[dev])
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess)
+            return e;
+        attr_done[dev] = true;
+    }
+    const int64_t tiles = (a.M + G::TILE_OUT - 1) / G::TILE_OUT;
+    if (tiles <= 0)
+        return hipSuccess;
+    if (tiles > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(BLOCK), G::LDS_BYTES, a.stream,
+                       reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,
+                       reinterpret_cast<const f2 *>(a.hist), a.N, a.n0, a.M);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir(const LaunchArgs &a, int variant)
+{
+    if (a.backend == BACKEND_DIRECT)
+    {
+        // variant selects tuning alternatives of one (T, D) instantiation (bench/tests can sweep them)
+        if (a.T == 255 && a.D == 4)
+        {
+            switch (variant)
+            {
+            case 1: return launch_direct<255, 4, 8, 32, 256, false>(a);
+            case 2: return launch_direct<255, 4, 8, 32, 128, true>(a);
+            case 3: return launch_direct<255, 4, 8, 64, 256, true>(a);
+            default: return launch_direct<255, 4, 8, 32, 256, true>(a);
+            }
+        }
+        if (a.T == 255 && a.D == 1)
+        {
+            switch (variant)
+            {
+            case 1: return launch_direct<255, 1, 16, 32, 256, false>(a);
+            case 2: return launch_direct<255, 1, 8, 32, 256, true>(a);
+            default: return launch_direct<255, 1, 16, 32, 256, true>(a);
+            }
+        }
+        if (a.T == 127 && a.D == 1)
+        {
+            switch (variant)
+            {
+            case 1: return launch_direct<127, 1, 16, 32, 256, false>(a);
+            case 2: return launch_direct<127, 1, 8, 32, 256, true>(a);
+            default: return launch_direct<127, 1, 16, 32, 256, true>(a);
+            }
+        }
+        if (a.T == 127 && a.D == 4)
+            return launch_direct<127, 4, 8, 32, 256, true>(a);
+        return hipErrorInvalidConfiguration;
+    }
+    if (a.backend == BACKEND_GENERIC)
+    {
+        if (a.M <= 0)
+            return hipSuccess;
+        const int64_t blocks = (a.M + 255) / 256;
+        if (blocks > 0x7fffffffLL)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(fir_generic_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, a.stream,
+                           reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,
+                           reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidConfiguration;
+}
+
+bool direct_supported(int T, int D)
+{
+    return (T == 255 || T == 127) && (D == 1 || D == 4);
+}
+
+hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, hipStream_t stream)
+{
+    if (T <= 1)
+        return hipSuccess;
+    const int blocks = (T - 1 + 255) / 256;
+    hipLaunchKernelGGL(fir_history_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const f2 *>(in),
+                       reinterpret_cast<const f2 *>(hist_in), reinterpret_cast<f2 *>(hist_out), T, N);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(void *iq, uint64_t first, uint64_t count, uint32_t channel, const float *tone10,
+                        hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    ToneTable t;
+    for (int i = 0; i < 10; i++)
+        t.v[i] = tone10[i];
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<f2 *>(iq), first,
+                       count, 0x5130303100000000ULL + (uint64_t)channel, t);
+    return hipGetLastError();
+}
+
+} // namespace if_fir

@@ -1,0 +1,476 @@
+// if_fir_shim.cpp — the thin C-ABI over the HIP kernels (include/if_fir.h).  No CPU fallback: every entry point
+// that filters needs a HIP device; failures return 0 with a message in if_fir_last_error().
+//
+// BUILD-DEFINED boundary: the reference has no filter surface to mirror; conventions (uint8_t
+// status 1/0, Hungarian prefixes) follow /root/reference/software/upconverter/src/f1958.c:12-27.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "if_fir.h"
+#include "if_fir_kernels.h"
+
+#define IF_FIR_API extern "C" __attribute__((visibility("default")))
+
+struct if_fir_ctx
+{
+    int device;
+    hipStream_t own_stream;
+    hipStream_t stream;
+    int T, D;
+    uint32_t backend_req;
+    uint32_t backend;
+    int variant;
+    float *d_taps;
+    void *d_hist[2];
+    int hist_cur;
+    uint64_t consumed;
+    uint64_t max_samples;
+    void *d_stage_in;
+    void *d_stage_out;
+    float tone[10];
+    char info[128];
+    mutable char err[256];
+};
+
+static thread_local char g_init_err[256] = "";
+
+static void set_err(const if_fir_ctx *ctx, const char *fmt, ...)
+{
+    char *dst = ctx ? ctx->err : g_init_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 256, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do                                                                                          \
+    {                                                                                           \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+        {                                                                                       \
+            set_err(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 0;                                                                           \
+        }                                                                                       \
+    } while (0)
+
+static uint32_t resolve_backend(const if_fir_ctx *ctx, uint32_t req)
+{
+    if (req == IF_FIR_BACKEND_AUTO)
+        return if_fir::direct_supported(ctx->T, ctx->D) ? IF_FIR_BACKEND_HIP_DIRECT : IF_FIR_BACKEND_HIP_GENERIC;
+    return req;
+}
+
+static bool backend_ok(const if_fir_ctx *ctx, uint32_t b)
+{
+    switch (b)
+    {
+    case IF_FIR_BACKEND_HIP_DIRECT:
+        return if_fir::direct_supported(ctx->T, ctx->D);
+    case IF_FIR_BACKEND_HIP_GENERIC:
+        return true;
+    default:
+        return false; // TAPSPLIT / FFT: not built yet in this round's library
+    }
+}
+
+static void tone_table(float *t)
+{
+    for (int i = 0; i < 5; i++)
+    {
+        const double a1 = 2.0 * M_PI * 0.2 * (double)i, a2 = 2.0 * M_PI * 0.4 * (double)i;
+        t[2 * i + 0] = (float)(0.5 * cos(a1) + 0.5 * cos(a2));
+        t[2 * i + 1] = (float)(0.5 * sin(a1) + 0.5 * sin(a2));
+    }
+}
+
+IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t ulTaps, uint32_t ulDecimation,
+                               uint64_t ullMaxSamples, int32_t lDevice)
+{
+    if (ppCtx)
+        *ppCtx = nullptr;
+    if (!ppCtx || !pfTaps)
+    {
+        set_err(nullptr, "if_fir_init: NULL argument");
+        return 0;
+    }
+    if (ulTaps < 1 || ulTaps > IF_FIR_MAX_TAPS || ulDecimation < 1 || ulDecimation > IF_FIR_MAX_DECIMATION)
+    {
+        set_err(nullptr, "if_fir_init: taps must be 1..%u and decimation 1..%u (got %u, %u)", IF_FIR_MAX_TAPS,
+                IF_FIR_MAX_DECIMATION, ulTaps, ulDecimation);
+        return 0;
+    }
+    for (uint32_t i = 0; i < ulTaps; i++)
+        if (!std::isfinite(pfTaps[i]))
+        {
+            set_err(nullptr, "if_fir_init: tap %u is not finite", i);
+            return 0;
+        }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+    {
+        set_err(nullptr, "if_fir_init: no HIP device available (%s); libif_fir has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return 0;
+    }
+    if (lDevice < 0 || lDevice >= ndev)
+    {
+        set_err(nullptr, "if_fir_init: device %d out of range (0..%d)", lDevice, ndev - 1);
+        return 0;
+    }
+    if_fir_ctx *ctx = new (std::nothrow) if_fir_ctx();
+    if (!ctx)
+    {
+        set_err(nullptr, "if_fir_init: out of host memory");
+        return 0;
+    }
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->device = lDevice;
+    ctx->T = (int)ulTaps;
+    ctx->D = (int)ulDecimation;
+    ctx->max_samples = ullMaxSamples;
+    tone_table(ctx->tone);
+
+#define INIT_TRY(call)                                                                               \
+    do                                                                                               \
+    {                                                                                                \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+        {                                                                                            \
+            set_err(nullptr, "if_fir_init: %s failed: %s", #call, hipGetErrorString(e_));            \
+            if_fir_destroy(ctx);                                                                     \
+            return 0;                                                                                \
+        }                                                                                            \
+    } while (0)
+
+    INIT_TRY(hipSetDevice(lDevice));
+    hipDeviceProp_t prop;
+    INIT_TRY(hipGetDeviceProperties(&prop, lDevice));
+    snprintf(ctx->info, sizeof(ctx->info), "%s %s cus=%d clock_mhz=%d lds_per_block=%zu", prop.name, prop.gcnArchName,
+             prop.multiProcessorCount, prop.clockRate / 1000, (size_t)prop.sharedMemPerBlock);
+    INIT_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    INIT_TRY(hipMalloc((void **)&ctx->d_taps, sizeof(float) * ulTaps));
+    INIT_TRY(hipMemcpy(ctx->d_taps, pfTaps, sizeof(float) * ulTaps, hipMemcpyHostToDevice));
+    const size_t hist_bytes = 8 * (size_t)(ulTaps > 1 ? ulTaps - 1 : 1);
+    for (int i = 0; i < 2; i++)
+    {
+        INIT_TRY(hipMalloc(&ctx->d_hist[i], hist_bytes));
+        INIT_TRY(hipMemset(ctx->d_hist[i], 0, hist_bytes));
+    }
+#undef INIT_TRY
+    ctx->backend_req = IF_FIR_BACKEND_AUTO;
+    ctx->backend = resolve_backend(ctx, IF_FIR_BACKEND_AUTO);
+    const char *v = getenv("IF_FIR_VARIANT");
+    ctx->variant = v ? atoi(v) : 0;
+    ctx->err[0] = 0;
+    *ppCtx = ctx;
+    return 1;
+}
+
+IF_FIR_API void if_fir_destroy(if_fir_ctx_t *pCtx)
+{
+    if (!pCtx)
+        return;
+    (void)hipSetDevice(pCtx->device);
+    if (pCtx->own_stream)
+    {
+        (void)hipStreamSynchronize(pCtx->own_stream);
+        (void)hipStreamDestroy(pCtx->own_stream);
+    }
+    if (pCtx->d_taps)
+        (void)hipFree(pCtx->d_taps);
+    for (int i = 0; i < 2; i++)
+        if (pCtx->d_hist[i])
+            (void)hipFree(pCtx->d_hist[i]);
+    if (pCtx->d_stage_in)
+        (void)hipFree(pCtx->d_stage_in);
+    if (pCtx->d_stage_out)
+        (void)hipFree(pCtx->d_stage_out);
+    delete pCtx;
+}
+
+IF_FIR_API const char *if_fir_last_error(const if_fir_ctx_t *pCtx)
+{
+    return pCtx ? pCtx->err : g_init_err;
+}
+
+IF_FIR_API uint8_t if_fir_reset(if_fir_ctx_t *pCtx)
+{
+    if (!pCtx)
+        return 0;
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    const size_t hist_bytes = 8 * (size_t)(pCtx->T > 1 ? pCtx->T - 1 : 1);
+    for (int i = 0; i < 2; i++)
+        HIP_TRY(pCtx, hipMemsetAsync(pCtx->d_hist[i], 0, hist_bytes, pCtx->stream));
+    pCtx->hist_cur = 0;
+    pCtx->consumed = 0;
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_set_backend(if_fir_ctx_t *pCtx, uint32_t ulBackend)
+{
+    if (!pCtx)
+        return 0;
+    const uint32_t b = resolve_backend(pCtx, ulBackend);
+    if (!backend_ok(pCtx, b))
+    {
+        set_err(pCtx, "if_fir_set_backend: backend %u does not support taps=%d decimation=%d", ulBackend, pCtx->T,
+                pCtx->D);
+        return 0;
+    }
+    pCtx->backend_req = ulBackend;
+    pCtx->backend = b;
+    return 1;
+}
+
+IF_FIR_API uint32_t if_fir_get_backend(const if_fir_ctx_t *pCtx)
+{
+    return pCtx ? pCtx->backend : 0;
+}
+
+IF_FIR_API uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant)
+{
+    if (!pCtx)
+        return 0;
+    pCtx->variant = (int)ulVariant;
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_set_stream(if_fir_ctx_t *pCtx, void *pStream)
+{
+    if (!pCtx)
+        return 0;
+    pCtx->stream = pStream ? (hipStream_t)pStream : pCtx->own_stream;
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_synchronize(if_fir_ctx_t *pCtx)
+{
+    if (!pCtx)
+        return 0;
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+    return 1;
+}
+
+static inline uint64_t out_count(uint64_t consumed, uint64_t n, uint32_t d, uint32_t *pn0)
+{
+    const uint64_t n0 = (d - consumed % d) % d;
+    if (pn0)
+        *pn0 = (uint32_t)n0;
+    return (n > n0) ? (n - n0 + d - 1) / d : 0;
+}
+
+IF_FIR_API uint64_t if_fir_out_count(const if_fir_ctx_t *pCtx, uint64_t ullSamples)
+{
+    if (!pCtx)
+        return 0;
+    return out_count(pCtx->consumed, ullSamples, (uint32_t)pCtx->D, nullptr);
+}
+
+// one launch of filter + history kernels; commit = advance the stream state
+static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n, uint64_t *pout, bool commit)
+{
+    if (n > (uint64_t)1 << 40)
+    {
+        set_err(ctx, "if_fir_process_device: sample count too large");
+        return 0;
+    }
+    if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+    {
+        set_err(ctx, "if_fir_process_device: device pointers must be 16-byte aligned");
+        return 0;
+    }
+    uint32_t n0 = 0;
+    const uint64_t m = out_count(ctx->consumed, n, (uint32_t)ctx->D, &n0);
+    if (pout)
+        *pout = m;
+    if (n == 0)
+        return 1;
+    if_fir::LaunchArgs a;
+    a.in = in;
+    a.out = out;
+    a.taps = ctx->d_taps;
+    a.hist = ctx->d_hist[ctx->hist_cur];
+    a.T = ctx->T;
+    a.D = ctx->D;
+    a.N = (int64_t)n;
+    a.n0 = (int32_t)n0;
+    a.M = (int64_t)m;
+    a.backend = (int)ctx->backend;
+    a.device = ctx->device;
+    a.stream = ctx->stream;
+    HIP_TRY(ctx, if_fir::launch_fir(a, ctx->variant));
+    HIP_TRY(ctx, if_fir::launch_history(in, ctx->d_hist[ctx->hist_cur], ctx->d_hist[ctx->hist_cur ^ 1], ctx->T,
+                                        (int64_t)n, ctx->stream));
+    if (commit)
+    {
+        ctx->hist_cur ^= 1;
+        ctx->consumed += n;
+    }
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_process_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
+                                         uint64_t *pullOutSamples)
+{
+    if (!pCtx)
+        return 0;
+    if (pullOutSamples)
+        *pullOutSamples = 0;
+    if (ullSamples && (!pDevIn || !pDevOut))
+    {
+        set_err(pCtx, "if_fir_process_device: NULL buffer");
+        return 0;
+    }
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    return run_device(pCtx, pDevIn, pDevOut, ullSamples, pullOutSamples, true);
+}
+
+IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float *pfIQOut, uint64_t ullSamples,
+                                  uint64_t *pullOutSamples)
+{
+    if (!pCtx)
+        return 0;
+    if (pullOutSamples)
+        *pullOutSamples = 0;
+    if (ullSamples == 0)
+        return 1;
+    if (!pfIQIn || !pfIQOut)
+    {
+        set_err(pCtx, "if_fir_process: NULL buffer");
+        return 0;
+    }
+    if (ullSamples > pCtx->max_samples)
+    {
+        set_err(pCtx, "if_fir_process: %llu samples exceed the ullMaxSamples=%llu given to if_fir_init",
+                (unsigned long long)ullSamples, (unsigned long long)pCtx->max_samples);
+        return 0;
+    }
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    if (!pCtx->d_stage_in)
+    {
+        HIP_TRY(pCtx, hipMalloc(&pCtx->d_stage_in, 8 * pCtx->max_samples));
+        HIP_TRY(pCtx, hipMalloc(&pCtx->d_stage_out, 8 * (pCtx->max_samples / pCtx->D + 1)));
+    }
+    HIP_TRY(pCtx, hipMemcpyAsync(pCtx->d_stage_in, pfIQIn, 8 * ullSamples, hipMemcpyHostToDevice, pCtx->stream));
+    uint64_t m = 0;
+    if (!run_device(pCtx, pCtx->d_stage_in, pCtx->d_stage_out, ullSamples, &m, true))
+        return 0;
+    if (m)
+        HIP_TRY(pCtx, hipMemcpyAsync(pfIQOut, pCtx->d_stage_out, 8 * m, hipMemcpyDeviceToHost, pCtx->stream));
+    HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+    if (pullOutSamples)
+        *pullOutSamples = m;
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_synth_device(if_fir_ctx_t *pCtx, void *pDevIQ, uint64_t ullFirst, uint64_t ullSamples,
+                                       uint32_t ulChannel)
+{
+    if (!pCtx)
+        return 0;
+    if (ullSamples && !pDevIQ)
+    {
+        set_err(pCtx, "if_fir_synth_device: NULL buffer");
+        return 0;
+    }
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    HIP_TRY(pCtx, if_fir::launch_synth(pDevIQ, ullFirst, ullSamples, ulChannel, pCtx->tone, pCtx->stream));
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_time_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
+                                      uint32_t ulWarmup, uint32_t ulReps, float *pfMsPerCall)
+{
+    if (!pCtx)
+        return 0;
+    if (!pDevIn || !pDevOut || !pfMsPerCall || ulReps == 0 || ullSamples == 0)
+    {
+        set_err(pCtx, "if_fir_time_device: bad argument");
+        return 0;
+    }
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    hipEvent_t ev0, ev1;
+    HIP_TRY(pCtx, hipEventCreate(&ev0));
+    HIP_TRY(pCtx, hipEventCreate(&ev1));
+    uint8_t ok = 1;
+    for (uint32_t i = 0; i < ulWarmup && ok; i++)
+        ok = run_device(pCtx, pDevIn, pDevOut, ullSamples, nullptr, false);
+    if (ok && hipEventRecord(ev0, pCtx->stream) != hipSuccess)
+        ok = 0;
+    for (uint32_t i = 0; i < ulReps && ok; i++)
+        ok = run_device(pCtx, pDevIn, pDevOut, ullSamples, nullptr, false);
+    if (ok && hipEventRecord(ev1, pCtx->stream) != hipSuccess)
+        ok = 0;
+    if (ok && hipEventSynchronize(ev1) != hipSuccess)
+        ok = 0;
+    float ms = 0.f;
+    if (ok && hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess)
+        ok = 0;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (!ok)
+    {
+        if (!pCtx->err[0])
+            set_err(pCtx, "if_fir_time_device: HIP event timing failed");
+        return 0;
+    }
+    *pfMsPerCall = ms / (float)ulReps;
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_dev_alloc(if_fir_ctx_t *pCtx, void **ppDev, uint64_t ullBytes)
+{
+    if (!pCtx || !ppDev)
+        return 0;
+    *ppDev = nullptr;
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    HIP_TRY(pCtx, hipMalloc(ppDev, ullBytes ? ullBytes : 16));
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_dev_free(if_fir_ctx_t *pCtx, void *pDev)
+{
+    if (!pCtx)
+        return 0;
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    HIP_TRY(pCtx, hipFree(pDev));
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_dev_upload(if_fir_ctx_t *pCtx, void *pDev, const void *pHost, uint64_t ullBytes)
+{
+    if (!pCtx)
+        return 0;
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    HIP_TRY(pCtx, hipMemcpyAsync(pDev, pHost, ullBytes, hipMemcpyHostToDevice, pCtx->stream));
+    HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_dev_download(if_fir_ctx_t *pCtx, void *pHost, const void *pDev, uint64_t ullBytes)
+{
+    if (!pCtx)
+        return 0;
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    HIP_TRY(pCtx, hipMemcpyAsync(pHost, pDev, ullBytes, hipMemcpyDeviceToHost, pCtx->stream));
+    HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOutBytes)
+{
+    if (!pCtx || !pszOut || !ulOutBytes)
+        return 0;
+    snprintf(pszOut, ulOutBytes, "%s", pCtx->info);
+    return 1;
+}

@@ -1,0 +1,208 @@
+"""ctypes binding of libif_fir.so — one Python method per C entry point of include/if_fir.h (same names, same
+argument meaning, 1/0 status turned into IfFirError).  No compute happens here."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libif_fir.so")
+
+BACKEND_AUTO, BACKEND_HIP_DIRECT, BACKEND_HIP_TAPSPLIT, BACKEND_HIP_GENERIC, BACKEND_HIP_FFT = range(5)
+WINDOW_RECT, WINDOW_HAMMING, WINDOW_HANN, WINDOW_BLACKMAN = range(4)
+
+# every symbol include/if_fir.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "if_bpf_design", "if_fir_init", "if_fir_destroy", "if_fir_reset", "if_fir_set_backend", "if_fir_get_backend",
+    "if_fir_set_tuning", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
+    "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
+    "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info",
+]
+
+
+class IfFirError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libif_fir.so (raises if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IfFirError("libif_fir.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                         % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    u8, u32, u64, i32, vp = ctypes.c_uint8, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p
+    f32p = ctypes.POINTER(ctypes.c_float)
+    L.if_bpf_design.argtypes = [f32p, u32, ctypes.c_double, ctypes.c_double, u32]
+    L.if_bpf_design.restype = u8
+    L.if_fir_init.argtypes = [ctypes.POINTER(vp), f32p, u32, u32, u64, i32]
+    L.if_fir_init.restype = u8
+    L.if_fir_destroy.argtypes = [vp]
+    L.if_fir_destroy.restype = None
+    L.if_fir_reset.argtypes = [vp]
+    L.if_fir_reset.restype = u8
+    L.if_fir_set_backend.argtypes = [vp, u32]
+    L.if_fir_set_backend.restype = u8
+    L.if_fir_get_backend.argtypes = [vp]
+    L.if_fir_get_backend.restype = u32
+    L.if_fir_set_tuning.argtypes = [vp, u32]
+    L.if_fir_set_tuning.restype = u8
+    L.if_fir_set_stream.argtypes = [vp, vp]
+    L.if_fir_set_stream.restype = u8
+    L.if_fir_synchronize.argtypes = [vp]
+    L.if_fir_synchronize.restype = u8
+    L.if_fir_last_error.argtypes = [vp]
+    L.if_fir_last_error.restype = ctypes.c_char_p
+    L.if_fir_out_count.argtypes = [vp, u64]
+    L.if_fir_out_count.restype = u64
+    L.if_fir_process.argtypes = [vp, f32p, f32p, u64, ctypes.POINTER(u64)]
+    L.if_fir_process.restype = u8
+    L.if_fir_process_device.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64)]
+    L.if_fir_process_device.restype = u8
+    L.if_fir_synth_device.argtypes = [vp, vp, u64, u64, u32]
+    L.if_fir_synth_device.restype = u8
+    L.if_fir_time_device.argtypes = [vp, vp, vp, u64, u32, u32, f32p]
+    L.if_fir_time_device.restype = u8
+    L.if_fir_dev_alloc.argtypes = [vp, ctypes.POINTER(vp), u64]
+    L.if_fir_dev_alloc.restype = u8
+    L.if_fir_dev_free.argtypes = [vp, vp]
+    L.if_fir_dev_free.restype = u8
+    L.if_fir_dev_upload.argtypes = [vp, vp, vp, u64]
+    L.if_fir_dev_upload.restype = u8
+    L.if_fir_dev_download.argtypes = [vp, vp, vp, u64]
+    L.if_fir_dev_download.restype = u8
+    L.if_fir_device_info.argtypes = [vp, ctypes.c_char_p, u32]
+    L.if_fir_device_info.restype = u8
+    _lib = L
+    return L
+
+
+def _f32p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def bpf_design(taps, f_low=0.15, f_high=0.25, window=WINDOW_BLACKMAN):
+    """if_bpf_design(): windowed-sinc band-pass taps (float32)."""
+    h = np.zeros(max(int(taps), 0), dtype=np.float32)
+    if not lib().if_bpf_design(_f32p(h), int(taps), float(f_low), float(f_high), int(window)):
+        raise IfFirError("if_bpf_design rejected taps=%r band=[%r,%r] window=%r" % (taps, f_low, f_high, window))
+    return h
+
+
+class IfFir:
+    """One if_fir_ctx_t.  Methods mirror the C entry points."""
+
+    def __init__(self, taps, decimation=1, max_samples=1 << 20, device=0):
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        self._ctx = ctypes.c_void_p()
+        self.taps = taps
+        self.decimation = int(decimation)
+        ok = lib().if_fir_init(ctypes.byref(self._ctx), _f32p(taps), taps.size, self.decimation, int(max_samples),
+                               int(device))
+        if not ok:
+            self._ctx = ctypes.c_void_p()
+            raise IfFirError(lib().if_fir_last_error(None).decode())
+
+    def _check(self, ok):
+        if not ok:
+            raise IfFirError(lib().if_fir_last_error(self._ctx).decode())
+
+    def close(self):
+        if self._ctx:
+            lib().if_fir_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def reset(self):
+        self._check(lib().if_fir_reset(self._ctx))
+
+    def set_backend(self, backend):
+        self._check(lib().if_fir_set_backend(self._ctx, int(backend)))
+
+    def get_backend(self):
+        return int(lib().if_fir_get_backend(self._ctx))
+
+    def set_tuning(self, variant):
+        self._check(lib().if_fir_set_tuning(self._ctx, int(variant)))
+
+    def set_stream(self, stream_handle):
+        self._check(lib().if_fir_set_stream(self._ctx, ctypes.c_void_p(stream_handle or None)))
+
+    def synchronize(self):
+        self._check(lib().if_fir_synchronize(self._ctx))
+
+    def out_count(self, samples):
+        return int(lib().if_fir_out_count(self._ctx, int(samples)))
+
+    def device_info(self):
+        buf = ctypes.create_string_buffer(256)
+        self._check(lib().if_fir_device_info(self._ctx, buf, 256))
+        return buf.value.decode()
+
+    def process(self, iq):
+        """if_fir_process(): host interleaved float32 (or complex64) in, interleaved float32 out."""
+        iq = np.asarray(iq)
+        if np.iscomplexobj(iq):
+            iq = np.ascontiguousarray(iq.astype(np.complex64)).view(np.float32)
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        n = iq.size // 2
+        out = np.empty(2 * self.out_count(n), dtype=np.float32)
+        m = ctypes.c_uint64(0)
+        dummy = np.zeros(2, dtype=np.float32)
+        self._check(lib().if_fir_process(self._ctx, _f32p(iq if n else dummy), _f32p(out if out.size else dummy), n,
+                                         ctypes.byref(m)))
+        assert m.value * 2 == out.size
+        return out
+
+    def process_device(self, dev_in, dev_out, samples):
+        """if_fir_process_device(): raw device pointers (ints), asynchronous. Returns the output sample count."""
+        m = ctypes.c_uint64(0)
+        self._check(lib().if_fir_process_device(self._ctx, ctypes.c_void_p(dev_in), ctypes.c_void_p(dev_out),
+                                                int(samples), ctypes.byref(m)))
+        return int(m.value)
+
+    def synth_device(self, dev_iq, first, samples, channel=0):
+        self._check(lib().if_fir_synth_device(self._ctx, ctypes.c_void_p(dev_iq), int(first), int(samples),
+                                              int(channel)))
+
+    def time_device(self, dev_in, dev_out, samples, warmup=3, reps=10):
+        ms = ctypes.c_float(0)
+        self._check(lib().if_fir_time_device(self._ctx, ctypes.c_void_p(dev_in), ctypes.c_void_p(dev_out),
+                                             int(samples), int(warmup), int(reps), ctypes.byref(ms)))
+        return float(ms.value)
+
+    # device memory helpers (pure C hosts use these instead of HIP headers)
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._check(lib().if_fir_dev_alloc(self._ctx, ctypes.byref(p), int(nbytes)))
+        return p.value
+
+    def dev_free(self, ptr):
+        self._check(lib().if_fir_dev_free(self._ctx, ctypes.c_void_p(ptr)))
+
+    def dev_upload(self, ptr, host):
+        host = np.ascontiguousarray(host)
+        self._check(lib().if_fir_dev_upload(self._ctx, ctypes.c_void_p(ptr), host.ctypes.data_as(ctypes.c_void_p),
+                                            host.nbytes))
+
+    def dev_download(self, ptr, nbytes, dtype=np.float32):
+        host = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._check(lib().if_fir_dev_download(self._ctx, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
+                                              host.nbytes))
+        return host

@@ -1,0 +1,60 @@
+"""Full-size (BASELINE.json configs[1], configs[2]) property tests on the GPU: the oracle cannot run 2^28 samples in
+seconds, so parity is checked (a) exactly on windows of the stream against the oracle, (b) through size-independent
+properties: one call ≡ two calls at an odd split (tile placement independence, history/phase carry), and a checksum
+of the whole output that must not depend on the split."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEG = dict(seg_mode=1, seg_len=32)
+
+
+@pytest.mark.parametrize("t,d,log2n", [(127, 1, 26), (255, 4, 28), (255, 1, 26)])
+def test_full_size_windows_and_split_invariance(fir, oracle, gpu_ok, t, d, log2n):
+    import torch
+    torch.cuda.set_device(0)
+    n = 1 << log2n
+    taps = fir.bpf_design(t)
+    with fir.IfFir(taps, d, 0) as f:
+        x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+        m = f.out_count(n)
+        y = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        f.synth_device(x.data_ptr(), 0, n, 0)
+        assert f.process_device(x.data_ptr(), y.data_ptr(), n) == m
+        f.synchronize()
+        # (a) windows: start, tile seams, an arbitrary interior place, the very end
+        w = 4096
+        for start in [0, 8192 - 100, (n // 3) & ~3, n - w]:
+            lo = max(0, start - (t - 1))
+            xs = x[2 * lo:2 * (start + w)].cpu().numpy()
+            assert np.array_equal(xs, oracle.synth_iq(start + w - lo, 0, lo))
+            hist = np.zeros(2 * (t - 1), dtype=np.float32)
+            hist[2 * (t - 1 - (start - lo)):] = xs[:2 * (start - lo)]
+            model = oracle.fir_f32fma(taps, xs[2 * (start - lo):], d, hist, start, **SEG)
+            first_out = (start + d - 1) // d
+            got = y[2 * first_out:2 * first_out + model.size].cpu().numpy()
+            assert np.array_equal(got, model), (start, np.max(np.abs(got - model)))
+            ref = oracle.fir_f64(taps, xs[2 * (start - lo):], d, hist, start)
+            l2, mx = oracle.err_metrics(got, ref)
+            assert l2 <= 1e-6 and mx <= 1e-6
+        # (b) split invariance + checksum
+        ck1 = y.double().sum().item()
+        ab1 = y.double().abs().sum().item()
+        y2 = torch.empty_like(y)
+        f.reset()
+        cut = (n // 2) + 12345   # odd: second call starts off-phase and misaligned
+        m1 = f.process_device(x.data_ptr(), y2.data_ptr(), cut)
+        m2 = f.process_device(x.data_ptr() + 8 * cut, y2.data_ptr() + 8 * m1, n - cut) if cut % 2 == 0 else None
+        if m2 is None:
+            # device pointers must stay 16-byte aligned: move the tail to an aligned buffer
+            tail = x[2 * cut:].clone()
+            torch.cuda.synchronize()
+            ytail = torch.empty(2 * (m - m1), dtype=torch.float32, device="cuda")
+            m2 = f.process_device(tail.data_ptr(), ytail.data_ptr(), n - cut)
+            f.synchronize()
+            y2[2 * m1:] = ytail
+        f.synchronize()
+        assert m1 + m2 == m
+        assert torch.equal(y, y2)
+        assert y2.double().sum().item() == ck1 and y2.double().abs().sum().item() == ab1 and ab1 > 0

@@ -1,0 +1,196 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C-ABI of libif_fir.so and is compared
+with the oracle — bit-for-bit against the float32 fma-order model and within SPEC §3 tolerance of the float64 oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "if_fir_golden.npz")
+SEG = dict(seg_mode=1, seg_len=32)
+TOL = 1e-6  # SPEC §3 / north_star: 1e-6 relative (norm-wise and max-wise)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(gpu_ok):
+    import torch
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _check(oracle, y, taps, x, d, hist=None, consumed=0):
+    model = oracle.fir_f32fma(taps, x, d, hist, consumed, **SEG)
+    assert y.shape == model.shape
+    assert np.array_equal(y, model), "max |diff| vs order model = %g" % np.max(np.abs(y - model))
+    ref = oracle.fir_f64(taps, x, d, hist, consumed)
+    if ref.size and np.any(ref):
+        l2, mx = oracle.err_metrics(y, ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+
+
+def test_library_loaded_is_in_tree(fir, gpu_ok):
+    assert os.path.dirname(fir.LIB_PATH).endswith("qo-100-tools_amd") and fir.lib() is not None
+
+
+def test_synth_device_bit_exact(fir, oracle, torch_cuda):
+    torch = torch_cuda
+    with fir.IfFir(fir.bpf_design(127), 1, 1 << 16) as f:
+        for first, n, ch in [(0, 10007, 0), (123456789012, 4096, 7), (5, 1, 1), (2 ** 40 + 3, 70001, 255)]:
+            buf = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+            f.synth_device(buf.data_ptr(), first, n, ch)
+            f.synchronize()
+            assert np.array_equal(buf.cpu().numpy(), oracle.synth_iq(n, ch, first))
+
+
+@pytest.mark.parametrize("t,d", [(255, 4), (255, 1), (127, 1), (127, 4)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_direct_kernels_vs_oracle(fir, oracle, t, d, variant):
+    taps = fir.bpf_design(t)
+    rng = np.random.default_rng(100 * t + d)
+    n = 70_001
+    x = np.concatenate([oracle.synth_iq(n // 2), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
+    with fir.IfFir(taps, d, n) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_DIRECT
+        f.set_tuning(variant)
+        _check(oracle, f.process(x), taps, x, d)
+
+
+@pytest.mark.parametrize("t,d", [(1, 1), (2, 2), (31, 3), (64, 1), (255, 5), (1023, 1), (1023, 4), (4096, 64)])
+def test_generic_kernel_vs_oracle(fir, oracle, t, d):
+    rng = np.random.default_rng(t + d)
+    taps = (fir.bpf_design(t) if t % 2 and t >= 3 else rng.standard_normal(t).astype(np.float32) / t)
+    n = 20_011
+    x = rng.standard_normal(2 * n).astype(np.float32)
+    with fir.IfFir(taps, d, n) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_GENERIC
+        _check(oracle, f.process(x), taps, x, d)
+
+
+def test_generic_backend_forced_equals_direct(fir, oracle):
+    taps = fir.bpf_design(255)
+    x = oracle.synth_iq(30_000, 2)
+    with fir.IfFir(taps, 4, 30_000) as f:
+        a = f.process(x)
+        f.reset()
+        f.set_backend(fir.BACKEND_HIP_GENERIC)
+        b = f.process(x)
+        assert np.array_equal(a, b)
+        with pytest.raises(fir.IfFirError):
+            f.set_backend(fir.BACKEND_HIP_FFT)   # not built this round: must say so, context stays usable
+        f.reset()
+        assert np.array_equal(f.process(x), b)
+
+
+@pytest.mark.parametrize("t", [127, 255, 1023])
+@pytest.mark.parametrize("d", [1, 4])
+def test_golden_vectors(fir, oracle, t, d):
+    g = np.load(GOLD)
+    taps, x, ref = g["taps_%d" % t], g["x"], g["y_T%d_D%d" % (t, d)]
+    with fir.IfFir(taps, d, 4096) as f:
+        y = f.process(x)
+    l2, mx = oracle.err_metrics(y, ref)
+    assert l2 <= TOL and mx <= TOL, (l2, mx)
+
+
+def test_config0_real_samples_through_complex_path(fir, oracle):
+    """BASELINE configs[0]: 127 taps over 2^20 real float samples (I = x, Q = 0)."""
+    g = np.load(GOLD)
+    taps = g["taps_127"]
+    xr = oracle.synth_iq(1 << 20)[0::2].copy()
+    x = np.zeros(2 * xr.size, dtype=np.float32)
+    x[0::2] = xr
+    with fir.IfFir(taps, 1, xr.size) as f:
+        y = f.process(x)
+    ref = oracle.fir_real_f64(taps, xr)
+    l2, mx = oracle.err_metrics(y[0::2], ref)
+    assert l2 <= TOL and mx <= TOL and not np.any(y[1::2])
+    # and the committed 4096-sample real fixture
+    x4 = np.zeros(2 * 4096, dtype=np.float32)
+    x4[0::2] = g["xr"]
+    with fir.IfFir(taps, 1, 4096) as f:
+        l2, mx = oracle.err_metrics(f.process(x4)[0::2], g["yr_T127"])
+    assert l2 <= TOL and mx <= TOL
+
+
+@pytest.mark.parametrize("t,d", [(255, 4), (255, 1), (127, 1), (31, 3)])
+def test_streaming_ragged_pieces(fir, oracle, t, d):
+    """process(a‖b‖…) ≡ process(a), process(b), …  — history and decimation phase carried, including empty pieces,
+    pieces shorter than the history, odd lengths (misaligned phase) and tile-boundary lengths."""
+    taps = fir.bpf_design(t)
+    n = 40_000
+    x = oracle.synth_iq(n, 1)
+    one = oracle.fir_f32fma(taps, x, d, **SEG)
+    cuts = [0, 0, 1, 3, 10, 11, 200, 253, 254, 255, 511, 8192 + 511, 8192 + 512, 2 * 8192 + 513, 30_001, n]
+    with fir.IfFir(taps, d, n) as f:
+        parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts), one)
+        f.reset()
+        assert np.array_equal(f.process(x), one)   # reset restores zero history and phase 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 254, 255, 256, 2047, 2048, 2049, 8191, 8192, 8193, 16384, 24577])
+def test_sizes_around_tile_edges(fir, oracle, n):
+    for t, d in [(255, 4), (255, 1)]:
+        taps = fir.bpf_design(t)
+        x = oracle.synth_iq(n, 3)
+        with fir.IfFir(taps, d, n) as f:
+            _check(oracle, f.process(x), taps, x, d)
+
+
+def test_impulse_and_zero_input(fir, oracle):
+    taps = fir.bpf_design(255)
+    x = np.zeros(2 * 1000, dtype=np.float32)
+    x[0], x[1] = 1.0, -2.0
+    with fir.IfFir(taps, 1, 1000) as f:
+        y = f.process(x)
+        assert np.array_equal(y[0:510:2], taps) and np.array_equal(y[1:510:2], -2 * taps) and not np.any(y[510:])
+        assert f.process(np.zeros(0, dtype=np.float32)).size == 0
+        assert not np.any(f.process(np.zeros(2 * 600, dtype=np.float32))[2 * 255:])
+
+
+def test_device_api_canaries_and_errors(fir, oracle, torch_cuda):
+    """process_device on raw pointers: outputs land exactly in [0, M) (guard words untouched), misaligned pointers
+    are refused with a message, and the context keeps working afterwards."""
+    torch = torch_cuda
+    taps = fir.bpf_design(255)
+    n, d = 50_001, 4
+    x = oracle.synth_iq(n, 4)
+    m = oracle.out_count(0, n, d)
+    guard = 1024
+    xin = torch.from_numpy(x).cuda()
+    out = torch.full((2 * m + 2 * guard,), 12345.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with fir.IfFir(taps, d, n) as f:
+        with pytest.raises(fir.IfFirError, match="aligned"):
+            f.process_device(xin.data_ptr() + 4, out.data_ptr(), n - 1)
+        got = f.process_device(xin.data_ptr(), out.data_ptr() + 4 * guard, n)
+        f.synchronize()
+        assert got == m
+        o = out.cpu().numpy()
+        assert np.all(o[:guard] == 12345.0) and np.all(o[guard + 2 * m:] == 12345.0)
+        assert np.array_equal(o[guard:guard + 2 * m], oracle.fir_f32fma(taps, x, d, **SEG))
+        ms = f.time_device(xin.data_ptr(), out.data_ptr(), n, 1, 3)   # timing helper leaves the stream state alone
+        assert ms > 0
+        again = f.process_device(xin.data_ptr(), out.data_ptr(), n)
+        f.synchronize()
+        st = oracle.OracleStream(taps, d)
+        st.process(x, "f32", **SEG)
+        assert np.array_equal(out.cpu().numpy()[:2 * again], st.process(x, "f32", **SEG))
+    with pytest.raises(fir.IfFirError):
+        fir.IfFir(taps, 4, n, device=99)
+
+
+def test_caller_stream(fir, oracle, torch_cuda):
+    torch = torch_cuda
+    taps = fir.bpf_design(127)
+    n = 20_000
+    x = oracle.synth_iq(n)
+    s = torch.cuda.Stream()
+    with fir.IfFir(taps, 1, n) as f, torch.cuda.stream(s):
+        f.set_stream(s.cuda_stream)
+        xin = torch.from_numpy(x).cuda(non_blocking=False)
+        out = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+        f.process_device(xin.data_ptr(), out.data_ptr(), n)
+        s.synchronize()
+        assert np.array_equal(out.cpu().numpy(), oracle.fir_f32fma(taps, x, 1, **SEG))

@@ -1,0 +1,56 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/if_fir.h declares, the C tap
+designer matches the oracle and the golden taps, and the library fails loudly (no CPU fallback) without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "if_fir_golden.npz")
+
+
+def test_library_exports_every_declared_symbol(fir):
+    header = open(os.path.join(ROOT, "include", "if_fir.h")).read()
+    declared = set(re.findall(r"\b(if_(?:fir|bpf)_[a-z_]+)\s*\(", header))
+    assert declared == set(fir.EXPORTS), declared ^ set(fir.EXPORTS)
+    lib = fir.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_library_does_not_link_the_oracle_or_torch():
+    import subprocess
+    so = os.path.join(ROOT, "qo-100-tools_amd", "libif_fir.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "oracle" not in needed and "torch" not in needed and "amdhip64" in needed
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    assert "oracle_" not in syms
+
+
+@pytest.mark.parametrize("t", [127, 255, 1023])
+def test_c_designer_matches_oracle_and_golden(fir, oracle, t):
+    h = fir.bpf_design(t)
+    assert np.array_equal(h, oracle.bpf_design(t))
+    assert np.array_equal(h, np.load(GOLD)["taps_%d" % t])
+    for win, name in [(fir.WINDOW_RECT, "rect"), (fir.WINDOW_HAMMING, "hamming"), (fir.WINDOW_HANN, "hann")]:
+        assert np.array_equal(fir.bpf_design(t, 0.1, 0.3, win), oracle.bpf_design(t, 0.1, 0.3, name))
+
+
+def test_c_designer_rejects_bad_arguments(fir):
+    for args in [(128,), (1,), (0,), (4097,), (127, 0.3, 0.2), (127, 0.1, 0.6), (127, -0.1, 0.2), (127, 0.1, 0.2, 9)]:
+        with pytest.raises(fir.IfFirError):
+            fir.bpf_design(*args)
+
+
+def test_init_argument_errors_and_no_cpu_fallback(fir):
+    import torch
+    taps = fir.bpf_design(127)
+    for bad in [dict(taps=np.zeros(0, np.float32)), dict(taps=np.zeros(5000, np.float32)),
+                dict(taps=taps, decimation=0), dict(taps=taps, decimation=65),
+                dict(taps=np.array([1.0, np.nan], np.float32))]:
+        with pytest.raises(fir.IfFirError):
+            fir.IfFir(**bad)
+    if not torch.cuda.is_available():
+        with pytest.raises(fir.IfFirError, match="no HIP device"):
+            fir.IfFir(taps)   # must fail loudly, never fall back to a CPU path
