@@ -59,7 +59,7 @@ def cpu_baseline(taps_arr, decim, budget_s=12.0):
     except Exception:
         handle = None
     lib = handle or oracle.lib()
-    threads = oracle.max_threads()
+    threads = min(oracle.max_threads(), 16)   # a 1-GPU box's CPU share is 16 cores
     n = 1 << 24
     t = taps_arr.size
     buf = np.zeros(2 * (n + t - 1), dtype=np.float32)      # T-1 zero history in front of the stream (phase 0)
@@ -120,8 +120,9 @@ def main():
     f = fir.IfFir(taps, decim, 0, device=local_rank)
     if args.variant is not None:
         f.set_tuning(args.variant)
-    stream = torch.cuda.current_stream()
-    f.set_stream(stream.cuda_stream)     # kernels run on torch's current stream so torch.cuda.Event brackets them
+    stream = torch.cuda.Stream(device=dev)   # a real (non-null) HIP stream: handle 0 would mean "context's own stream"
+    torch.cuda.set_stream(stream)
+    f.set_stream(stream.cuda_stream)         # kernels run on this stream so the torch.cuda.Event pair brackets them
     m = f.out_count(n)
     x = torch.empty(2 * n, dtype=torch.float32, device=dev)
     y = torch.empty(2 * m, dtype=torch.float32, device=dev)

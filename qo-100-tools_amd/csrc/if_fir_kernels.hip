@@ -319,7 +319,7 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             {
             case 1: return launch_direct<255, 4, 8, 32, 256, false>(a);
             case 2: return launch_direct<255, 4, 8, 32, 128, true>(a);
-            case 3: return launch_direct<255, 4, 8, 64, 256, true>(a);
+            case 3: return launch_direct<255, 4, 8, 32, 128, false>(a);
             default: return launch_direct<255, 4, 8, 32, 256, true>(a);
             }
         }
