@@ -23,6 +23,8 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+#include "generated/if_fir_walk_gen.h"
+
 namespace if_fir
 {
 
@@ -203,6 +205,186 @@ __global__ __launch_bounds__(BLOCK) void fir_direct_kernel(const f2 *__restrict_
 }
 
 // --------------------------------------------------------------------------------------------------------------
+// direct-form kernel v2 — persistent, wave-private pipeline (no workgroup barriers)
+//
+// Each WAVE owns a private LDS window (halo + one tile of 64·R outputs) and walks a contiguous run of tiles:
+//   issue the global loads of tile i+1 into registers  →  walk tile i out of LDS (the FMA stream)  →
+//   move the last T-1 samples to the front of the window (halo carry: the stream is read from HBM exactly once)  →
+//   transpose the 64·R outputs through the dead part of the window and store them with 1 KiB-contiguous
+//   stores  →  write tile i+1 from registers into the window.
+// Waves never synchronise with each other, so the two waves that share a SIMD drift apart and one computes
+// while the other moves data.  A 256-thread workgroup is four such waves (one per SIMD); two workgroups fit a CU.
+// --------------------------------------------------------------------------------------------------------------
+template <int T, int D, int R>
+struct WGeo
+{
+    static constexpr int DR = D * R;
+    static constexpr int HALO = ((T - 1 + DR - 1) / DR) * DR;
+    static constexpr int HCH = HALO / DR;                 // halo chunks
+    static constexpr int CH = DR * 8 + 16;                // padded chunk stride (bytes)
+    static constexpr int TILE_OUT = 64 * R;
+    static constexpr int TILE_IN = 64 * DR;
+    static constexpr int NCH = 64 + HCH;
+    static constexpr int WAVE_LDS = NCH * CH;
+    static constexpr int OCH = R * 8 + 16;                // padded per-lane output chunk
+    static constexpr int OUT_OFF = HCH * CH;              // outputs are transposed through the (dead) tile area
+    static constexpr int TILE_UNITS = TILE_IN / 2;        // 16-byte units in one tile
+    static constexpr int LOADS = TILE_UNITS / 64;         // dwordx4 loads per lane per tile
+    static constexpr int HALO_UNITS = HCH * CH / 16;      // halo carry copies whole padded chunks
+    static_assert(DR % 4 == 0 && (T - 1) % 2 == 0, "see Geo");
+    static_assert(OUT_OFF + 64 * OCH <= 64 * CH, "output transposition must fit in the dead tile area");
+    static_assert(TILE_UNITS % 64 == 0 && (DR % 2) == 0, "tile must be a whole number of wave-wide 16-byte loads");
+};
+
+// LDS byte address of 16-byte unit p (= samples 2p, 2p+1) of the tile area, padded chunk layout
+template <typename G>
+__device__ __forceinline__ int tile_unit_addr(int p)
+{
+    const int u = 2 * p;
+    return (G::HCH + u / G::DR) * G::CH + (u % G::DR) * 8;
+}
+
+// selects one generated assembly walk (tools/gen_walk.py): V = schedule variant of the same arithmetic
+template <int T, int D, int R, int SEG, int V>
+struct AsmWalk;
+#define IF_FIR_ASM_WALK(T_, D_, R_, S_, V_, FN_)                                                       \
+    template <>                                                                                        \
+    struct AsmWalk<T_, D_, R_, S_, V_>                                                                 \
+    {                                                                                                  \
+        static __device__ __forceinline__ void run(unsigned a, const float *t, f2 (&tot)[R_]) { FN_(a, t, tot); } \
+    };
+IF_FIR_ASM_WALK(255, 4, 8, 32, 0, walk_asm_T255_D4_R8_S32)
+IF_FIR_ASM_WALK(255, 4, 8, 32, 1, walk_asm_T255_D4_R8_S32_q6)
+IF_FIR_ASM_WALK(255, 4, 8, 32, 2, walk_asm_T255_D4_R8_S32_b128)
+IF_FIR_ASM_WALK(255, 4, 8, 32, 3, walk_asm_T255_D4_R8_S32_b128q3)
+IF_FIR_ASM_WALK(255, 1, 8, 32, 0, walk_asm_T255_D1_R8_S32)
+IF_FIR_ASM_WALK(255, 1, 16, 32, 0, walk_asm_T255_D1_R16_S32)
+IF_FIR_ASM_WALK(127, 1, 8, 32, 0, walk_asm_T127_D1_R8_S32)
+IF_FIR_ASM_WALK(127, 1, 16, 32, 0, walk_asm_T127_D1_R16_S32)
+IF_FIR_ASM_WALK(127, 4, 8, 32, 0, walk_asm_T127_D4_R8_S32)
+
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+template <int T, int D, int R, int SEG, int PF>
+__global__ __launch_bounds__(256, 2) void fir_direct_wave_kernel(const f2 *__restrict__ in, f2 *__restrict__ out,
+                                                             const float *__restrict__ taps,
+                                                             const f2 *__restrict__ hist, int64_t N, int32_t n0,
+                                                             int64_t M, int64_t tiles_total, int32_t run_len,
+                                                             int32_t waves_total)
+{
+    using G = WGeo<T, D, R>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *wl = smem + wid * G::WAVE_LDS;                   // this wave's private window
+    // 32-bit LDS byte address of this lane's chunk (operand of the generated ds_read instructions)
+    const unsigned lds_lane_addr = (unsigned)(uintptr_t)(lds_char_t *)smem + (unsigned)(wid * G::WAVE_LDS + lane * G::CH);
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wid;
+    const bool aligned = ((n0 & 1) == 0);
+
+    for (int64_t run = gw; run * run_len < tiles_total; run += waves_total)
+    {
+        const int64_t t_first = run * run_len;
+        const int64_t t_last = (t_first + run_len < tiles_total) ? t_first + run_len : tiles_total;
+
+        // ---- prologue: halo + first tile of the run (bounds-checked 8-byte path; once per run) ----------------
+        {
+            const int64_t g0 = (int64_t)n0 + t_first * G::TILE_IN - G::HALO;
+            for (int p = lane; p < (G::HALO + G::TILE_IN) / 2; p += 64)
+            {
+                const int u = 2 * p;
+                const f2 a = fetch_sample(in, hist, T, g0 + u, N);
+                const f2 b = fetch_sample(in, hist, T, g0 + u + 1, N);
+                *reinterpret_cast<f4 *>(wl + (u / G::DR) * G::CH + (u % G::DR) * 8) = (f4){a.x, a.y, b.x, b.y};
+            }
+        }
+
+        for (int64_t t = t_first; t < t_last; t++)
+        {
+            const int64_t base_next = (int64_t)n0 + (t + 1) * G::TILE_IN; // first sample of tile t+1
+            const bool has_next = (t + 1 < t_last);
+            const bool next_fast = has_next && aligned && (base_next + G::TILE_IN <= N);
+
+            // ---- 1. prefetch tile t+1 into registers ----------------------------------------------------------
+            f4 nxt[G::LOADS];
+            if (next_fast)
+            {
+                const f4 *src = reinterpret_cast<const f4 *>(in + base_next) + lane;
+#pragma unroll
+                for (int i = 0; i < G::LOADS; i++)
+                    nxt[i] = src[i * 64];
+            }
+
+            // ---- 2. walk tile t (generated assembly: FMA stream with LDS reads prefetched into a register ring) --
+            f2 tot[R];
+            AsmWalk<T, D, R, SEG, PF>::run(lds_lane_addr, taps, tot);
+
+            // ---- 3. halo carry: last HCH chunks -> front of the window ----------------------------------------
+            if (has_next)
+            {
+                f4 hv[(G::HALO_UNITS + 63) / 64];
+#pragma unroll
+                for (int i = 0; i < (G::HALO_UNITS + 63) / 64; i++)
+                {
+                    const int p = lane + i * 64;
+                    if ((i + 1) * 64 <= G::HALO_UNITS || p < G::HALO_UNITS)
+                        hv[i] = *reinterpret_cast<const f4 *>(wl + 64 * G::CH + p * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < (G::HALO_UNITS + 63) / 64; i++)
+                {
+                    const int p = lane + i * 64;
+                    if ((i + 1) * 64 <= G::HALO_UNITS || p < G::HALO_UNITS)
+                        *reinterpret_cast<f4 *>(wl + p * 16) = hv[i];
+                }
+            }
+
+            // ---- 4. outputs: transpose through LDS, 1 KiB-contiguous stores -------------------------------------
+            {
+                char *o = wl + G::OUT_OFF + lane * G::OCH;
+#pragma unroll
+                for (int r = 0; r < R; r += 2)
+                    *reinterpret_cast<f4 *>(o + r * 8) = (f4){tot[r].x, tot[r].y, tot[r + 1].x, tot[r + 1].y};
+                const int64_t m_tile = t * G::TILE_OUT;
+                const bool full = (m_tile + G::TILE_OUT <= M);
+#pragma unroll
+                for (int i = 0; i < R / 2; i++)
+                {
+                    const int e = 2 * (lane + 64 * i); // output index inside the tile
+                    const f4 v = *reinterpret_cast<const f4 *>(wl + G::OUT_OFF + (e / R) * G::OCH + (e % R) * 8);
+                    if (full)
+                        *reinterpret_cast<f4 *>(out + m_tile + e) = v;
+                    else
+                    {
+                        if (m_tile + e < M)
+                            out[m_tile + e] = (f2){v.x, v.y};
+                        if (m_tile + e + 1 < M)
+                            out[m_tile + e + 1] = (f2){v.z, v.w};
+                    }
+                }
+            }
+
+            // ---- 5. tile t+1 into the window ------------------------------------------------------------------
+            if (next_fast)
+            {
+#pragma unroll
+                for (int i = 0; i < G::LOADS; i++)
+                    *reinterpret_cast<f4 *>(wl + tile_unit_addr<G>(lane + 64 * i)) = nxt[i];
+            }
+            else if (has_next)
+            {
+                for (int p = lane; p < G::TILE_UNITS; p += 64)
+                {
+                    const f2 a = fetch_sample(in, hist, T, base_next + 2 * p, N);
+                    const f2 b = fetch_sample(in, hist, T, base_next + 2 * p + 1, N);
+                    *reinterpret_cast<f4 *>(wl + tile_unit_addr<G>(p)) = (f4){a.x, a.y, b.x, b.y};
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
 // generic kernel: any T ≤ 4096, any D ≤ 64.  One output per thread, taps read through the scalar cache
 // (uniform index), samples straight from global/L2 (neighbouring lanes share lines).  Same summation order
 // as the fast kernels (descending k, segments of SEG).  Correctness fallback, not a performance path.
@@ -308,6 +490,52 @@ static hipError_t launch_direct(const LaunchArgs &a)
     return hipGetLastError();
 }
 
+template <int T, int D, int R, int SEG, int PF>
+static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
+{
+    using G = WGeo<T, D, R>;
+    auto kern = fir_direct_wave_kernel<T, D, R, SEG, PF>;
+    constexpr int LDS = 4 * G::WAVE_LDS;
+    static bool attr_done[16] = {false};
+    static int cus[16] = {0};
+    const int dev = a.device & 15;
+    if (!attr_done[dev])
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess)
+            return e;
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, a.device);
+        if (e != hipSuccess)
+            return e;
+        cus[dev] = prop.multiProcessorCount;
+        attr_done[dev] = true;
+    }
+    const int64_t tiles = (a.M + G::TILE_OUT - 1) / G::TILE_OUT;
+    if (tiles <= 0)
+        return hipSuccess;
+    const int blocks_per_cu = (160 * 1024) / LDS > 0 ? (160 * 1024) / LDS : 1;
+    int64_t blocks = (int64_t)cus[dev] * blocks_per_cu;
+    int64_t waves = blocks * 4;
+    // contiguous run per wave: by default the whole share of a wave (halo read once), capped by run_len_arg
+    int64_t run_len = (tiles + waves - 1) / waves;
+    if (run_len_arg > 0 && run_len > run_len_arg)
+        run_len = run_len_arg;
+    if (run_len < 1)
+        run_len = 1;
+    const int64_t runs = (tiles + run_len - 1) / run_len;
+    if (runs < waves)
+    {
+        blocks = (runs + 3) / 4;
+        waves = blocks * 4;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, a.stream, reinterpret_cast<const f2 *>(a.in),
+                       reinterpret_cast<f2 *>(a.out), a.taps, reinterpret_cast<const f2 *>(a.hist), a.N, a.n0, a.M,
+                       tiles, (int32_t)run_len, (int32_t)waves);
+    return hipGetLastError();
+}
+
 hipError_t launch_fir(const LaunchArgs &a, int variant)
 {
     if (a.backend == BACKEND_DIRECT)
@@ -319,8 +547,13 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             {
             case 1: return launch_direct<255, 4, 8, 32, 256, false>(a);
             case 2: return launch_direct<255, 4, 8, 32, 128, true>(a);
-            case 3: return launch_direct<255, 4, 8, 32, 128, false>(a);
-            default: return launch_direct<255, 4, 8, 32, 256, true>(a);
+            case 3: return launch_direct<255, 4, 8, 32, 256, true>(a);
+            case 4: return launch_wave<255, 4, 8, 32, 1>(a, 0);
+            case 5: return launch_wave<255, 4, 8, 32, 2>(a, 0);
+            case 6: return launch_wave<255, 4, 8, 32, 3>(a, 0);
+            case 7: return launch_wave<255, 4, 8, 32, 0>(a, 8);
+            case 8: return launch_wave<255, 4, 8, 32, 0>(a, 1);
+            default: return launch_wave<255, 4, 8, 32, 0>(a, 0);
             }
         }
         if (a.T == 255 && a.D == 1)

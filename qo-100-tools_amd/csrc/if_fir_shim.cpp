@@ -157,7 +157,10 @@ IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32
              prop.multiProcessorCount, prop.clockRate / 1000, (size_t)prop.sharedMemPerBlock);
     INIT_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    INIT_TRY(hipMalloc((void **)&ctx->d_taps, sizeof(float) * ulTaps));
+    // taps are fetched in whole 16-float blocks by s_load_dwordx16: pad the device copy with zeros to a multiple of 64
+    const size_t taps_padded = ((size_t)ulTaps + 63) / 64 * 64;
+    INIT_TRY(hipMalloc((void **)&ctx->d_taps, sizeof(float) * taps_padded));
+    INIT_TRY(hipMemset(ctx->d_taps, 0, sizeof(float) * taps_padded));
     INIT_TRY(hipMemcpy(ctx->d_taps, pfTaps, sizeof(float) * ulTaps, hipMemcpyHostToDevice));
     const size_t hist_bytes = 8 * (size_t)(ulTaps > 1 ? ulTaps - 1 : 1);
     for (int i = 0; i < 2; i++)
