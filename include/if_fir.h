@@ -107,6 +107,10 @@ uint8_t if_fir_dev_alloc(if_fir_ctx_t *pCtx, void **ppDev, uint64_t ullBytes);
 uint8_t if_fir_dev_free(if_fir_ctx_t *pCtx, void *pDev);
 uint8_t if_fir_dev_upload(if_fir_ctx_t *pCtx, void *pDev, const void *pHost, uint64_t ullBytes);
 uint8_t if_fir_dev_download(if_fir_ctx_t *pCtx, void *pHost, const void *pDev, uint64_t ullBytes);
+/* Diagnostics (development aid): first call with pullOut = NULL arms per-wave start/end time stamps for the
+ * persistent direct-form kernel; later calls copy the last launch's stamps (4 x uint64 per wave) and return the
+ * number of words written. */
+uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulWords);
 /* "gfx950", CU count, etc.: writes a short description of the context's device */
 uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOutBytes);
 

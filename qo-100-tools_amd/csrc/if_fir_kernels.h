@@ -28,6 +28,8 @@ struct LaunchArgs
     int backend;
     int device;
     hipStream_t stream;
+    void *queue; // device, 16 bytes: atomic run queue of the persistent kernel (zeroed by the launcher)
+    void *dbg; // optional diagnostic stamp buffer (8192 x 4 x u64) or nullptr
 };
 
 bool direct_supported(int T, int D);

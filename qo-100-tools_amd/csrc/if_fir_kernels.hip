@@ -232,7 +232,8 @@ struct WGeo
     static constexpr int LOADS = TILE_UNITS / 64;         // dwordx4 loads per lane per tile
     static constexpr int HALO_UNITS = HCH * CH / 16;      // halo carry copies whole padded chunks
     static_assert(DR % 4 == 0 && (T - 1) % 2 == 0, "see Geo");
-    static_assert(OUT_OFF + 64 * OCH <= 64 * CH, "output transposition must fit in the dead tile area");
+    // the outputs are staged after the halo carry, when the whole tile area [OUT_OFF, WAVE_LDS) is dead
+    static_assert(OUT_OFF + 64 * OCH <= WAVE_LDS, "output transposition must fit in the dead tile area");
     static_assert(TILE_UNITS % 64 == 0 && (DR % 2) == 0, "tile must be a whole number of wave-wide 16-byte loads");
 };
 
@@ -265,15 +266,36 @@ IF_FIR_ASM_WALK(127, 4, 8, 32, 0, walk_asm_T127_D4_R8_S32)
 
 typedef __attribute__((address_space(3))) char lds_char_t;
 
-template <int T, int D, int R, int SEG, int PF>
-__global__ __launch_bounds__(256, 2) void fir_direct_wave_kernel(const f2 *__restrict__ in, f2 *__restrict__ out,
-                                                             const float *__restrict__ taps,
-                                                             const f2 *__restrict__ hist, int64_t N, int32_t n0,
-                                                             int64_t M, int64_t tiles_total, int32_t run_len,
-                                                             int32_t waves_total)
+// fill `count` 16-byte units of the wave's window starting at LDS unit index `unit0` (padded chunk layout, unit 0 =
+// first halo sample pair) from stream sample g_first on, with bounds/history checks (slow path: edges only)
+template <typename G>
+__device__ __forceinline__ void fill_slow(char *wl, int lane, int unit0, int count, const f2 *__restrict__ in,
+                                          const f2 *__restrict__ hist, int T, int64_t g_first, int64_t N)
+{
+    for (int p = lane; p < count; p += 64)
+    {
+        const int u = 2 * (unit0 + p);
+        const f2 a = fetch_sample(in, hist, T, g_first + 2 * p, N);
+        const f2 b = fetch_sample(in, hist, T, g_first + 2 * p + 1, N);
+        *reinterpret_cast<f4 *>(wl + (u / G::DR) * G::CH + (u % G::DR) * 8) = (f4){a.x, a.y, b.x, b.y};
+    }
+}
+
+template <int T, int D, int R, int SEG, int V, int WPS>
+__global__ __launch_bounds__(256, WPS) void fir_direct_wave_kernel(const f2 *__restrict__ in, f2 *__restrict__ out,
+                                                                  const float *__restrict__ taps,
+                                                                  const f2 *__restrict__ hist, int64_t N, int32_t n0,
+                                                                  int64_t M, int64_t tiles_total, int32_t run_len,
+                                                                  int32_t waves_total, unsigned int *queue,
+                                                                  unsigned long long *dbg)
 {
     using G = WGeo<T, D, R>;
+    constexpr int HU = G::HALO / 2;                        // 16-byte units in the halo
+    constexpr int HL = (HU + 63) / 64;                     // halo loads per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // diagnostic stamps (only when the host passes a buffer; they go nowhere else): start/end of this wave
+    const unsigned long long st_real = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long st_clk = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *wl = smem + wid * G::WAVE_LDS;                   // this wave's private window
@@ -281,47 +303,72 @@ __global__ __launch_bounds__(256, 2) void fir_direct_wave_kernel(const f2 *__res
     const unsigned lds_lane_addr = (unsigned)(uintptr_t)(lds_char_t *)smem + (unsigned)(wid * G::WAVE_LDS + lane * G::CH);
     const int64_t gw = (int64_t)blockIdx.x * 4 + wid;
     const bool aligned = ((n0 & 1) == 0);
+    const int64_t runs_total = (tiles_total + run_len - 1) / run_len;
 
-    for (int64_t run = gw; run * run_len < tiles_total; run += waves_total)
+    // Work distribution: run r = tiles [r*run_len, (r+1)*run_len).  Wave gw starts with run gw; further runs come from
+    // an atomic queue, always grabbed one run ahead so the atomic's latency hides behind a whole run.  (The two
+    // waves sharing a SIMD do not progress at the same speed — the older one wins issue arbitration — so a static
+    // split leaves half the chip idle at the end.)
+    int64_t run = gw;
+    unsigned int ticket = 0;
+    bool have_ticket = false;
+    if (run < runs_total)
+    {
+        // ---- prologue: halo + first tile of the first run (bounds-checked path; once per wave) -----------------
+        fill_slow<G>(wl, lane, 0, HU + G::TILE_UNITS, in, hist, T, (int64_t)n0 + run * run_len * G::TILE_IN - G::HALO, N);
+    }
+    while (run < runs_total)
     {
         const int64_t t_first = run * run_len;
         const int64_t t_last = (t_first + run_len < tiles_total) ? t_first + run_len : tiles_total;
-
-        // ---- prologue: halo + first tile of the run (bounds-checked 8-byte path; once per run) ----------------
-        {
-            const int64_t g0 = (int64_t)n0 + t_first * G::TILE_IN - G::HALO;
-            for (int p = lane; p < (G::HALO + G::TILE_IN) / 2; p += 64)
-            {
-                const int u = 2 * p;
-                const f2 a = fetch_sample(in, hist, T, g0 + u, N);
-                const f2 b = fetch_sample(in, hist, T, g0 + u + 1, N);
-                *reinterpret_cast<f4 *>(wl + (u / G::DR) * G::CH + (u % G::DR) * 8) = (f4){a.x, a.y, b.x, b.y};
-            }
-        }
+        if (lane == 0)
+            ticket = atomicAdd(queue, 1u);                  // reservation for the run after this one
+        have_ticket = true;
+        int64_t next_run = runs_total;                      // resolved when the current run reaches its last tile
 
         for (int64_t t = t_first; t < t_last; t++)
         {
-            const int64_t base_next = (int64_t)n0 + (t + 1) * G::TILE_IN; // first sample of tile t+1
-            const bool has_next = (t + 1 < t_last);
-            const bool next_fast = has_next && aligned && (base_next + G::TILE_IN <= N);
+            // ---- 0. which tile comes next? ----------------------------------------------------------------------
+            bool contiguous = (t + 1 < t_last);
+            int64_t t_next = t + 1;
+            if (!contiguous)
+            {
+                next_run = (int64_t)waves_total + (int64_t)__builtin_amdgcn_readfirstlane(ticket);
+                have_ticket = false;
+                t_next = next_run * run_len;
+            }
+            const bool has_next = contiguous || (next_run < runs_total);
+            const int64_t base_next = (int64_t)n0 + t_next * G::TILE_IN; // first sample of the next tile
+            const bool next_fast = has_next && aligned && (base_next + G::TILE_IN <= N) &&
+                                   (contiguous || base_next - G::HALO >= 0);
 
-            // ---- 1. prefetch tile t+1 into registers ----------------------------------------------------------
+            // ---- 1. prefetch the next tile (and its halo when it starts a new run) into registers --------------
             f4 nxt[G::LOADS];
+            f4 nh[HL];
             if (next_fast)
             {
                 const f4 *src = reinterpret_cast<const f4 *>(in + base_next) + lane;
 #pragma unroll
                 for (int i = 0; i < G::LOADS; i++)
                     nxt[i] = src[i * 64];
+                if (!contiguous)
+                {
+                    const f4 *hsrc = reinterpret_cast<const f4 *>(in + base_next - G::HALO) + lane;
+#pragma unroll
+                    for (int i = 0; i < HL; i++)
+                        if ((i + 1) * 64 <= HU || lane + i * 64 < HU)
+                            nh[i] = hsrc[i * 64];
+                }
             }
 
             // ---- 2. walk tile t (generated assembly: FMA stream with LDS reads prefetched into a register ring) --
             f2 tot[R];
-            AsmWalk<T, D, R, SEG, PF>::run(lds_lane_addr, taps, tot);
+            AsmWalk<T, D, R, SEG, V>::run(lds_lane_addr, taps, tot);
 
-            // ---- 3. halo carry: last HCH chunks -> front of the window ----------------------------------------
-            if (has_next)
+            // ---- 3. halo for the next tile -----------------------------------------------------------------------
+            if (contiguous)
             {
+                // carry: last HCH chunks -> front of the window (the stream is read from HBM exactly once)
                 f4 hv[(G::HALO_UNITS + 63) / 64];
 #pragma unroll
                 for (int i = 0; i < (G::HALO_UNITS + 63) / 64; i++)
@@ -336,6 +383,16 @@ __global__ __launch_bounds__(256, 2) void fir_direct_wave_kernel(const f2 *__res
                     const int p = lane + i * 64;
                     if ((i + 1) * 64 <= G::HALO_UNITS || p < G::HALO_UNITS)
                         *reinterpret_cast<f4 *>(wl + p * 16) = hv[i];
+                }
+            }
+            else if (next_fast)
+            {
+#pragma unroll
+                for (int i = 0; i < HL; i++)
+                {
+                    const int u = 2 * (lane + i * 64);
+                    if ((i + 1) * 64 <= HU || lane + i * 64 < HU)
+                        *reinterpret_cast<f4 *>(wl + (u / G::DR) * G::CH + (u % G::DR) * 8) = nh[i];
                 }
             }
 
@@ -364,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void fir_direct_wave_kernel(const f2 *__res
                 }
             }
 
-            // ---- 5. tile t+1 into the window ------------------------------------------------------------------
+            // ---- 5. next tile into the window ------------------------------------------------------------------
             if (next_fast)
             {
 #pragma unroll
@@ -373,14 +430,22 @@ __global__ __launch_bounds__(256, 2) void fir_direct_wave_kernel(const f2 *__res
             }
             else if (has_next)
             {
-                for (int p = lane; p < G::TILE_UNITS; p += 64)
-                {
-                    const f2 a = fetch_sample(in, hist, T, base_next + 2 * p, N);
-                    const f2 b = fetch_sample(in, hist, T, base_next + 2 * p + 1, N);
-                    *reinterpret_cast<f4 *>(wl + tile_unit_addr<G>(p)) = (f4){a.x, a.y, b.x, b.y};
-                }
+                if (contiguous)
+                    fill_slow<G>(wl, lane, HU, G::TILE_UNITS, in, hist, T, base_next, N);
+                else
+                    fill_slow<G>(wl, lane, 0, HU + G::TILE_UNITS, in, hist, T, base_next - G::HALO, N);
             }
         }
+        run = next_run;
+    }
+    (void)have_ticket;
+    if (dbg && (threadIdx.x & 63) == 0)
+    {
+        const long long gwi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        dbg[4 * gwi + 0] = st_real;
+        dbg[4 * gwi + 1] = __builtin_amdgcn_s_memrealtime();
+        dbg[4 * gwi + 2] = st_clk;
+        dbg[4 * gwi + 3] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -490,12 +555,15 @@ static hipError_t launch_direct(const LaunchArgs &a)
     return hipGetLastError();
 }
 
-template <int T, int D, int R, int SEG, int PF>
+template <int T, int D, int R, int SEG, int V>
 static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
 {
     using G = WGeo<T, D, R>;
-    auto kern = fir_direct_wave_kernel<T, D, R, SEG, PF>;
     constexpr int LDS = 4 * G::WAVE_LDS;
+    constexpr int BPC = (160 * 1024) / LDS;                 // workgroups (of 4 waves) per CU by LDS
+    static_assert(BPC >= 1, "window too large");
+    constexpr int WPS = BPC >= 2 ? 2 : 1;                   // waves per SIMD the register budget is sized for
+    auto kern = fir_direct_wave_kernel<T, D, R, SEG, V, WPS>;
     static bool attr_done[16] = {false};
     static int cus[16] = {0};
     const int dev = a.device & 15;
@@ -515,24 +583,25 @@ static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
     const int64_t tiles = (a.M + G::TILE_OUT - 1) / G::TILE_OUT;
     if (tiles <= 0)
         return hipSuccess;
-    const int blocks_per_cu = (160 * 1024) / LDS > 0 ? (160 * 1024) / LDS : 1;
-    int64_t blocks = (int64_t)cus[dev] * blocks_per_cu;
+    int64_t blocks = (int64_t)cus[dev] * (BPC > 2 ? 2 : BPC);
     int64_t waves = blocks * 4;
-    // contiguous run per wave: by default the whole share of a wave (halo read once), capped by run_len_arg
-    int64_t run_len = (tiles + waves - 1) / waves;
-    if (run_len_arg > 0 && run_len > run_len_arg)
-        run_len = run_len_arg;
-    if (run_len < 1)
-        run_len = 1;
+    int64_t run_len = run_len_arg > 0 ? run_len_arg : 4;
+    const int64_t per_wave = (tiles + waves - 1) / waves;
+    if (run_len > per_wave)
+        run_len = per_wave;
     const int64_t runs = (tiles + run_len - 1) / run_len;
     if (runs < waves)
     {
         blocks = (runs + 3) / 4;
         waves = blocks * 4;
     }
+    hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream); // run queue: re-zeroed before every launch
+    if (e != hipSuccess)
+        return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, a.stream, reinterpret_cast<const f2 *>(a.in),
                        reinterpret_cast<f2 *>(a.out), a.taps, reinterpret_cast<const f2 *>(a.hist), a.N, a.n0, a.M,
-                       tiles, (int32_t)run_len, (int32_t)waves);
+                       tiles, (int32_t)run_len, (int32_t)waves, (unsigned int *)a.queue,
+                       (unsigned long long *)a.dbg);
     return hipGetLastError();
 }
 
@@ -548,12 +617,13 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             case 1: return launch_direct<255, 4, 8, 32, 256, false>(a);
             case 2: return launch_direct<255, 4, 8, 32, 128, true>(a);
             case 3: return launch_direct<255, 4, 8, 32, 256, true>(a);
-            case 4: return launch_wave<255, 4, 8, 32, 1>(a, 0);
-            case 5: return launch_wave<255, 4, 8, 32, 2>(a, 0);
-            case 6: return launch_wave<255, 4, 8, 32, 3>(a, 0);
-            case 7: return launch_wave<255, 4, 8, 32, 0>(a, 8);
-            case 8: return launch_wave<255, 4, 8, 32, 0>(a, 1);
-            default: return launch_wave<255, 4, 8, 32, 0>(a, 0);
+            case 4: return launch_wave<255, 4, 8, 32, 1>(a, 4);
+            case 5: return launch_wave<255, 4, 8, 32, 0>(a, 4);
+            case 6: return launch_wave<255, 4, 8, 32, 3>(a, 4);
+            case 7: return launch_wave<255, 4, 8, 32, 2>(a, 2);
+            case 8: return launch_wave<255, 4, 8, 32, 2>(a, 8);
+            case 9: return launch_wave<255, 4, 8, 32, 2>(a, 1);
+            default: return launch_wave<255, 4, 8, 32, 2>(a, 4);
             }
         }
         if (a.T == 255 && a.D == 1)
@@ -562,6 +632,10 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             {
             case 1: return launch_direct<255, 1, 16, 32, 256, false>(a);
             case 2: return launch_direct<255, 1, 8, 32, 256, true>(a);
+            case 3: return launch_wave<255, 1, 16, 32, 0>(a, 4);
+            case 4: return launch_wave<255, 1, 8, 32, 0>(a, 4);
+            case 5: return launch_wave<255, 1, 16, 32, 0>(a, 8);
+            case 6: return launch_wave<255, 1, 16, 32, 0>(a, 2);
             default: return launch_direct<255, 1, 16, 32, 256, true>(a);
             }
         }
@@ -571,11 +645,21 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             {
             case 1: return launch_direct<127, 1, 16, 32, 256, false>(a);
             case 2: return launch_direct<127, 1, 8, 32, 256, true>(a);
+            case 3: return launch_wave<127, 1, 16, 32, 0>(a, 4);
+            case 4: return launch_wave<127, 1, 8, 32, 0>(a, 4);
+            case 5: return launch_wave<127, 1, 16, 32, 0>(a, 8);
+            case 6: return launch_wave<127, 1, 16, 32, 0>(a, 2);
             default: return launch_direct<127, 1, 16, 32, 256, true>(a);
             }
         }
         if (a.T == 127 && a.D == 4)
-            return launch_direct<127, 4, 8, 32, 256, true>(a);
+        {
+            switch (variant)
+            {
+            case 1: return launch_direct<127, 4, 8, 32, 256, true>(a);
+            default: return launch_wave<127, 4, 8, 32, 0>(a, 4);
+            }
+        }
         return hipErrorInvalidConfiguration;
     }
     if (a.backend == BACKEND_GENERIC)

@@ -34,6 +34,8 @@ struct if_fir_ctx
     void *d_stage_in;
     void *d_stage_out;
     float tone[10];
+    void *d_queue; // atomic run queue of the persistent kernel
+    void *d_dbg; // diagnostic wave stamps (if_fir_debug_stamps)
     char info[128];
     mutable char err[256];
 };
@@ -162,6 +164,8 @@ IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32
     INIT_TRY(hipMalloc((void **)&ctx->d_taps, sizeof(float) * taps_padded));
     INIT_TRY(hipMemset(ctx->d_taps, 0, sizeof(float) * taps_padded));
     INIT_TRY(hipMemcpy(ctx->d_taps, pfTaps, sizeof(float) * ulTaps, hipMemcpyHostToDevice));
+    INIT_TRY(hipMalloc(&ctx->d_queue, 16));
+    INIT_TRY(hipMemset(ctx->d_queue, 0, 16));
     const size_t hist_bytes = 8 * (size_t)(ulTaps > 1 ? ulTaps - 1 : 1);
     for (int i = 0; i < 2; i++)
     {
@@ -197,6 +201,10 @@ IF_FIR_API void if_fir_destroy(if_fir_ctx_t *pCtx)
         (void)hipFree(pCtx->d_stage_in);
     if (pCtx->d_stage_out)
         (void)hipFree(pCtx->d_stage_out);
+    if (pCtx->d_dbg)
+        (void)hipFree(pCtx->d_dbg);
+    if (pCtx->d_queue)
+        (void)hipFree(pCtx->d_queue);
     delete pCtx;
 }
 
@@ -311,6 +319,8 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.backend = (int)ctx->backend;
     a.device = ctx->device;
     a.stream = ctx->stream;
+    a.queue = ctx->d_queue;
+    a.dbg = ctx->d_dbg;
     HIP_TRY(ctx, if_fir::launch_fir(a, ctx->variant));
     HIP_TRY(ctx, if_fir::launch_history(in, ctx->d_hist[ctx->hist_cur], ctx->d_hist[ctx->hist_cur ^ 1], ctx->T,
                                         (int64_t)n, ctx->stream));
@@ -476,4 +486,33 @@ IF_FIR_API uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, ui
         return 0;
     snprintf(pszOut, ulOutBytes, "%s", pCtx->info);
     return 1;
+}
+
+// Diagnostics: the first call (pullOut == NULL or ulWords == 0) arms per-wave start/end stamps for the persistent
+// direct kernel; later calls copy the stamps of the last launch (4 x uint64 per wave: realtime start/end in 10 ns
+// ticks, shader clock start/end) and return the number of uint64 words written.
+IF_FIR_API uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulWords)
+{
+    if (!pCtx)
+        return 0;
+    const uint32_t max_words = 8192 * 4;
+    if (hipSetDevice(pCtx->device) != hipSuccess)
+        return 0;
+    if (!pCtx->d_dbg)
+    {
+        if (hipMalloc(&pCtx->d_dbg, sizeof(uint64_t) * max_words) != hipSuccess)
+        {
+            pCtx->d_dbg = nullptr;
+            return 0;
+        }
+        (void)hipMemset(pCtx->d_dbg, 0, sizeof(uint64_t) * max_words);
+    }
+    if (!pullOut || !ulWords)
+        return 0;
+    const uint32_t n = ulWords < max_words ? ulWords : max_words;
+    if (hipStreamSynchronize(pCtx->stream) != hipSuccess)
+        return 0;
+    if (hipMemcpy(pullOut, pCtx->d_dbg, sizeof(uint64_t) * n, hipMemcpyDeviceToHost) != hipSuccess)
+        return 0;
+    return n;
 }

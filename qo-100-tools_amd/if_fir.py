@@ -16,7 +16,7 @@ EXPORTS = [
     "if_bpf_design", "if_fir_init", "if_fir_destroy", "if_fir_reset", "if_fir_set_backend", "if_fir_get_backend",
     "if_fir_set_tuning", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
-    "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info",
+    "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
 ]
 
 
@@ -76,6 +76,8 @@ def lib():
     L.if_fir_dev_upload.restype = u8
     L.if_fir_dev_download.argtypes = [vp, vp, vp, u64]
     L.if_fir_dev_download.restype = u8
+    L.if_fir_debug_stamps.argtypes = [vp, ctypes.POINTER(u64), u32]
+    L.if_fir_debug_stamps.restype = u32
     L.if_fir_device_info.argtypes = [vp, ctypes.c_char_p, u32]
     L.if_fir_device_info.restype = u8
     _lib = L
@@ -186,6 +188,15 @@ class IfFir:
         self._check(lib().if_fir_time_device(self._ctx, ctypes.c_void_p(dev_in), ctypes.c_void_p(dev_out),
                                              int(samples), int(warmup), int(reps), ctypes.byref(ms)))
         return float(ms.value)
+
+    def debug_stamps(self, waves=None):
+        """Arm (waves=None) or fetch the per-wave diagnostic stamps of the last persistent-kernel launch."""
+        if waves is None:
+            lib().if_fir_debug_stamps(self._ctx, None, 0)
+            return None
+        buf = np.zeros(4 * waves, dtype=np.uint64)
+        n = lib().if_fir_debug_stamps(self._ctx, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), buf.size)
+        return buf[:n].reshape(-1, 4)
 
     # device memory helpers (pure C hosts use these instead of HIP headers)
     def dev_alloc(self, nbytes):

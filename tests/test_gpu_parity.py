@@ -44,7 +44,7 @@ def test_synth_device_bit_exact(fir, oracle, torch_cuda):
 
 
 @pytest.mark.parametrize("t,d", [(255, 4), (255, 1), (127, 1), (127, 4)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", list(range(10)))
 def test_direct_kernels_vs_oracle(fir, oracle, t, d, variant):
     taps = fir.bpf_design(t)
     rng = np.random.default_rng(100 * t + d)

@@ -30,7 +30,6 @@ OUT = os.path.join(HERE, "..", "qo-100-tools_amd", "csrc", "generated", "if_fir_
 
 SGPR_RING_BASE = 36      # s[36:99]: 4 blocks x 16 taps
 SGPR_RING_BLOCKS = 4
-VGPR_TMP_BASE = 176      # v[176:...]: acc temporaries + sample ring (clobbered)
 
 
 def gen_walk(T, D, R, SEG, Q, U):
@@ -49,8 +48,9 @@ def gen_walk(T, D, R, SEG, Q, U):
         return (u // DR) * CH + (u % DR) * 8
 
     # ---- register map ---------------------------------------------------------------------------------------
-    acc_base = VGPR_TMP_BASE                     # acc[r] = v[acc_base+2r : +1]
     ring_slots = Q + 2
+    need = 2 * R + 2 * U * ring_slots
+    acc_base = (256 - need) & ~3                 # temporaries sit at the top of the arch VGPR file
     ring_base = acc_base + 2 * R                 # slot i = v[ring_base + 2*U*i ...]
     vtop = ring_base + 2 * U * ring_slots
     assert vtop <= 256, "out of VGPRs"
@@ -172,7 +172,7 @@ def gen_walk(T, D, R, SEG, Q, U):
                     emit("v_pk_add_f32 %s, %s, %s" % (tot(r), tot(r), acc(r)))
     assert n_fma == R * T, (n_fma, R * T)
     name = "walk_asm_T%d_D%d_R%d_S%d" % (T, D, R, SEG)
-    clobbers = ["v%d" % i for i in range(VGPR_TMP_BASE, vtop)]
+    clobbers = ["v%d" % i for i in range(acc_base, vtop)]
     clobbers += ["s%d" % i for i in range(SGPR_RING_BASE, SGPR_RING_BASE + 16 * SGPR_RING_BLOCKS)]
     return name, lines, clobbers, dict(T=T, D=D, R=R, SEG=SEG, Q=Q, U=U, fma=n_fma, reads=len(issued),
                                        drains=len(drain_at), vgpr_top=vtop)

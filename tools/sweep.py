@@ -10,7 +10,7 @@ import bench
 
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "fir255_dec4_2p28"
-    variants = [int(v) for v in sys.argv[2:]] or list(range(0, 9))
+    variants = [int(v) for v in sys.argv[2:]] or list(range(0, 7))
     taps_n, decim, log2n, _ = bench.WORKLOADS[wl]
     n = 1 << log2n
     fir = g.load_pkg().if_fir
