@@ -88,8 +88,8 @@ def cpu_baseline(taps_arr, decim, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="fir255_dec4_2p28", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (if_fir_set_tuning)")
     ap.add_argument("--scatter", action="store_true", help="also time RCCL scatter/gather of channels from rank 0")

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""collect_profiles.py — condenses rocprofv3 output under gpurun_out/ into the tracked summaries under profiles/.
+
+usage: python tools/collect_profiles.py <round tag> <workload> <kernel-trace dir> <pmc fetch dir> <pmc write dir>
+Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --stats), profiles/<tag>_kernel_trace_summary.json and
+updates profiles/traffic.json (HBM bytes per launch from the TCC counters, gfx950 correction applied:
+FETCH_SIZE counts 128-byte read requests as 64 bytes for 16-byte-per-lane streaming loads — calibrated in the same
+session on a float4 read kernel — so read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact for 16-byte stores).
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag, workload, ktrace, pfetch, pwrite = sys.argv[1:6]
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    stats = glob.glob(os.path.join(ktrace, "**", "*kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats, os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
+    trace = glob.glob(os.path.join(ktrace, "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(trace)) if "fir_direct" in r["Kernel_Name"] or "fir_fft" in r["Kernel_Name"]]
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    full = [d for d in durs if d > 0.5 * max(durs)]          # drop the small parity-check launch
+    summ = {"kernel": rows[0]["Kernel_Name"].split("(")[0], "launches": len(full),
+            "avg_us_all": sum(full) / len(full), "avg_us_last_half": sum(full[len(full) // 2:]) / (len(full) - len(full) // 2),
+            "min_us": min(full), "max_us": max(full), "durations_us": [round(d, 1) for d in full],
+            "vgpr": rows[0]["VGPR_Count"], "sgpr": rows[0]["SGPR_Count"], "lds_block_bytes": rows[0]["LDS_Block_Size"],
+            "grid": rows[0]["Grid_Size_X"], "workgroup": rows[0]["Workgroup_Size_X"]}
+    json.dump(summ, open(os.path.join(ROOT, "profiles", "%s_kernel_trace_summary.json" % tag), "w"), indent=1)
+
+    def counter(d, name):
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                if r["Counter_Name"] == name and ("fir_direct" in r["Kernel_Name"] or "fir_fft" in r["Kernel_Name"])]
+        vals = [v for v in vals if v > 0.5 * max(vals)]
+        return sum(vals) / len(vals), len(vals)
+
+    fetch_kb, nf = counter(pfetch, "FETCH_SIZE")
+    write_kb, nw = counter(pwrite, "WRITE_SIZE")
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    traffic[workload] = {
+        "round": tag, "FETCH_SIZE_KiB_per_launch": fetch_kb, "WRITE_SIZE_KiB_per_launch": write_kb,
+        "launches_averaged": [nf, nw],
+        "read_bytes_per_launch": 2.0 * fetch_kb * 1024.0, "write_bytes_per_launch": write_kb * 1024.0,
+        "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0,
+        "correction": "read bytes = 2 x FETCH_SIZE (gfx950, 16-byte-per-lane streaming loads; a float4 read of 2 GiB "
+                      "reported FETCH_SIZE = 1.000 GiB in the same session); WRITE_SIZE exact"}
+    json.dump(traffic, open(tpath, "w"), indent=1)
+    print(json.dumps(summ)[:400])
+    print(json.dumps(traffic[workload]))
+
+
+if __name__ == "__main__":
+    main()
