@@ -28,12 +28,19 @@ struct LaunchArgs
     int backend;
     int device;
     hipStream_t stream;
+    const void *fft_tables; // device, FFT_TABLE_FLOATS floats (overlap-save backend) or nullptr
     void *queue; // device, 16 bytes: atomic run queue of the persistent kernel (zeroed by the launcher)
     void *dbg; // optional diagnostic stamp buffer (8192 x 4 x u64) or nullptr
 };
 
 bool direct_supported(int T, int D);
 hipError_t launch_fir(const LaunchArgs &a, int variant);
+// overlap-save FFT backend (if_fir_fft.hip)
+constexpr int FFT_TABLE_FLOATS = 2 * 4096 * 2 + 2 * 256;
+bool fft_supported(int T, int D);
+hipError_t launch_fft(const LaunchArgs &a);
+void fft_build_tables(const float *taps, int T, float *tables);
+
 hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, hipStream_t stream);
 hipError_t launch_synth(void *iq, uint64_t first, uint64_t count, uint32_t channel, const float *tone10,
                         hipStream_t stream);

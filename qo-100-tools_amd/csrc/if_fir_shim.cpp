@@ -34,6 +34,8 @@ struct if_fir_ctx
     void *d_stage_in;
     void *d_stage_out;
     float tone[10];
+    float *h_taps; // host copy of the taps (FFT tables are built on demand)
+    void *d_fft_tables; // overlap-save backend tables (built on first use)
     void *d_queue; // atomic run queue of the persistent kernel
     void *d_dbg; // diagnostic wave stamps (if_fir_debug_stamps)
     char info[128];
@@ -77,8 +79,10 @@ static bool backend_ok(const if_fir_ctx *ctx, uint32_t b)
         return if_fir::direct_supported(ctx->T, ctx->D);
     case IF_FIR_BACKEND_HIP_GENERIC:
         return true;
+    case IF_FIR_BACKEND_HIP_FFT:
+        return if_fir::fft_supported(ctx->T, ctx->D);
     default:
-        return false; // TAPSPLIT / FFT: not built yet in this round's library
+        return false; // TAPSPLIT: not built in this round's library
     }
 }
 
@@ -139,6 +143,14 @@ IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32
     ctx->D = (int)ulDecimation;
     ctx->max_samples = ullMaxSamples;
     tone_table(ctx->tone);
+    ctx->h_taps = (float *)malloc(sizeof(float) * ulTaps);
+    if (!ctx->h_taps)
+    {
+        set_err(nullptr, "if_fir_init: out of host memory");
+        delete ctx;
+        return 0;
+    }
+    memcpy(ctx->h_taps, pfTaps, sizeof(float) * ulTaps);
 
 #define INIT_TRY(call)                                                                               \
     do                                                                                               \
@@ -205,6 +217,9 @@ IF_FIR_API void if_fir_destroy(if_fir_ctx_t *pCtx)
         (void)hipFree(pCtx->d_dbg);
     if (pCtx->d_queue)
         (void)hipFree(pCtx->d_queue);
+    if (pCtx->d_fft_tables)
+        (void)hipFree(pCtx->d_fft_tables);
+    free(pCtx->h_taps);
     delete pCtx;
 }
 
@@ -236,6 +251,28 @@ IF_FIR_API uint8_t if_fir_set_backend(if_fir_ctx_t *pCtx, uint32_t ulBackend)
         set_err(pCtx, "if_fir_set_backend: backend %u does not support taps=%d decimation=%d", ulBackend, pCtx->T,
                 pCtx->D);
         return 0;
+    }
+    if (b == IF_FIR_BACKEND_HIP_FFT && !pCtx->d_fft_tables)
+    {
+        // twiddles and FFT(taps)/4096 in the kernel's LDS image order, float64 math on the host, once
+        float *tab = (float *)malloc(sizeof(float) * if_fir::FFT_TABLE_FLOATS);
+        if (!tab)
+        {
+            set_err(pCtx, "if_fir_set_backend: out of host memory");
+            return 0;
+        }
+        if_fir::fft_build_tables(pCtx->h_taps, pCtx->T, tab);
+        hipError_t e = hipSetDevice(pCtx->device);
+        if (e == hipSuccess)
+            e = hipMalloc(&pCtx->d_fft_tables, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
+        if (e == hipSuccess)
+            e = hipMemcpy(pCtx->d_fft_tables, tab, sizeof(float) * if_fir::FFT_TABLE_FLOATS, hipMemcpyHostToDevice);
+        free(tab);
+        if (e != hipSuccess)
+        {
+            set_err(pCtx, "if_fir_set_backend: FFT table upload failed: %s", hipGetErrorString(e));
+            return 0;
+        }
     }
     pCtx->backend_req = ulBackend;
     pCtx->backend = b;
@@ -319,9 +356,13 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.backend = (int)ctx->backend;
     a.device = ctx->device;
     a.stream = ctx->stream;
+    a.fft_tables = ctx->d_fft_tables;
     a.queue = ctx->d_queue;
     a.dbg = ctx->d_dbg;
-    HIP_TRY(ctx, if_fir::launch_fir(a, ctx->variant));
+    if (ctx->backend == IF_FIR_BACKEND_HIP_FFT)
+        HIP_TRY(ctx, if_fir::launch_fft(a));
+    else
+        HIP_TRY(ctx, if_fir::launch_fir(a, ctx->variant));
     HIP_TRY(ctx, if_fir::launch_history(in, ctx->d_hist[ctx->hist_cur], ctx->d_hist[ctx->hist_cur ^ 1], ctx->T,
                                         (int64_t)n, ctx->stream));
     if (commit)

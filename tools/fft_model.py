@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""fft_model.py — numpy model of the wave-private 4096-point FFT data movement used by csrc/if_fir_fft.hip.
+
+One wave = 64 lanes x 64 registers = one 4096-point complex FFT, N = 16*16*16:
+    n = 256*n0 + 16*n1 + n2   (input),      k = k0 + 16*k1 + 256*k2   (output)
+  load      reg[row] of lane = x[64*row + lane]            -> n0 = row//4, rho = row%4, n1 = lane//16 + 4*rho, n2 = lane%16
+  pass 1    FFT16 over n0 (4 groups rho)                   -> slot (k0, rho);  twiddle W4096^((lane+64*rho)*k0)
+  exch 1    permlane32_swap + permlane16_swap              -> lane g=lane//16 keeps k0 = 4g+i; slot (i,c,b,rho), n1 = c+2b+4rho
+  pass 2    FFT16 over n1 (4 groups i)                     -> slot (i, k1);    twiddle W256^(n2*k1), n2 = lane%16
+  exch 2    16x16 transposition inside each 16-lane row (LDS) -> lane%16 = k1, slot (i, n2)
+  pass 3    FFT16 over n2                                  -> slot (i, k2):  X[(4g+i) + 16*(lane%16) + 256*k2]
+The inverse runs the mirror image and ends in the load layout.  This file checks the index algebra against numpy.fft
+and is the reference the HIP kernel was transcribed from (development tool; not product, not oracle)."""
+import numpy as np
+
+N = 4096
+W = lambda n, e: np.exp(-2j * np.pi * e / n)  # noqa: E731
+
+
+def swap32(vdst, src):
+    """v_permlane32_swap: lanes 32-63 of vdst <-> lanes 0-31 of src."""
+    a, b = vdst.copy(), src.copy()
+    a[32:], b[:32] = src[:32].copy(), vdst[32:].copy()
+    return a, b
+
+
+def swap16(vdst, src):
+    """v_permlane16_swap: odd 16-lane rows of vdst <-> even rows of src."""
+    a, b = vdst.copy(), src.copy()
+    for row in (0, 2):
+        a[16 * (row + 1):16 * (row + 2)] = src[16 * row:16 * (row + 1)]
+        b[16 * row:16 * (row + 1)] = vdst[16 * (row + 1):16 * (row + 2)]
+    return a, b
+
+
+def forward(x):
+    lane = np.arange(64)
+    reg = np.zeros((64, 64), dtype=np.complex128)       # reg[slot, lane]
+    for row in range(64):
+        reg[row] = x[64 * row + lane]
+    # pass 1: FFT16 over n0 for each rho; slot (k0, rho) := 4*k0 + rho
+    p1 = np.zeros_like(reg)
+    for rho in range(4):
+        a = np.fft.fft(reg[rho::4], axis=0)              # rows 4*n0+rho, n0 = 0..15
+        for k0 in range(16):
+            p1[4 * k0 + rho] = a[k0] * W(N, (lane + 64 * rho) * k0)
+    # exchange 1, stage A: pair slot (k0<8, rho) with (k0+8, rho), permlane32_swap(vdst = k0<8, src = k0+8)
+    e = p1.copy()
+    for k0 in range(8):
+        for rho in range(4):
+            e[4 * k0 + rho], e[4 * (k0 + 8) + rho] = swap32(e[4 * k0 + rho], e[4 * (k0 + 8) + rho])
+    # stage B: k0slot = i + 4c + 8b; pair (i, c=0, b, rho) with (i, c=1, b, rho), permlane16_swap(vdst = c0, src = c1)
+    for i in range(4):
+        for b in range(2):
+            for rho in range(4):
+                s0, s1 = 4 * (i + 8 * b) + rho, 4 * (i + 4 + 8 * b) + rho
+                e[s0], e[s1] = swap16(e[s0], e[s1])
+    # now lane g holds k0 = 4g+i; slot (i,c,b,rho) holds n1 = c + 2b + 4rho
+    p2 = np.zeros_like(reg)                              # slot (i, k1) := 16*i + k1
+    n2 = lane % 16
+    for i in range(4):
+        seq = np.zeros((16, 64), dtype=np.complex128)
+        for c in range(2):
+            for b in range(2):
+                for rho in range(4):
+                    seq[c + 2 * b + 4 * rho] = e[4 * (i + 4 * c + 8 * b) + rho]
+        a = np.fft.fft(seq, axis=0)
+        for k1 in range(16):
+            p2[16 * i + k1] = a[k1] * W(256, n2 * k1)
+    # exchange 2: inside each 16-lane row g: element (i, k1) at lane (g, n2) -> lane (g, k1), slot (i, n2)
+    e2 = np.zeros_like(reg)
+    for i in range(4):
+        for g in range(4):
+            blk = p2[16 * i:16 * i + 16, 16 * g:16 * g + 16]   # [k1, n2]
+            e2[16 * i:16 * i + 16, 16 * g:16 * g + 16] = blk.T  # [n2, k1]
+    # pass 3: FFT16 over n2 -> slot (i, k2)
+    p3 = np.zeros_like(reg)
+    for i in range(4):
+        p3[16 * i:16 * i + 16] = np.fft.fft(e2[16 * i:16 * i + 16], axis=0)
+    return p3
+
+
+def k_of(slot, lane):
+    i, k2 = slot // 16, slot % 16
+    return (4 * (lane // 16) + i) + 16 * (lane % 16) + 256 * k2
+
+
+def inverse(p3):
+    lane = np.arange(64)
+    n2 = lane % 16
+    # pass 3^-1
+    e2 = np.zeros_like(p3)
+    for i in range(4):
+        e2[16 * i:16 * i + 16] = np.fft.ifft(p3[16 * i:16 * i + 16], axis=0) * 16
+    # exchange 2 (same transposition), now element (i, n2) at lane (g,k1) -> lane (g,n2), slot (i,k1)
+    p2 = np.zeros_like(p3)
+    for i in range(4):
+        for g in range(4):
+            p2[16 * i:16 * i + 16, 16 * g:16 * g + 16] = e2[16 * i:16 * i + 16, 16 * g:16 * g + 16].T
+    e = np.zeros_like(p3)
+    for i in range(4):
+        seq = np.stack([p2[16 * i + k1] * np.conj(W(256, n2 * k1)) for k1 in range(16)])
+        a = np.fft.ifft(seq, axis=0) * 16                   # index n1
+        for c in range(2):
+            for b in range(2):
+                for rho in range(4):
+                    e[4 * (i + 4 * c + 8 * b) + rho] = a[c + 2 * b + 4 * rho]
+    # exchange 1 inverse: stage B then stage A (each an involution with the same pairing)
+    for i in range(4):
+        for b in range(2):
+            for rho in range(4):
+                s0, s1 = 4 * (i + 8 * b) + rho, 4 * (i + 4 + 8 * b) + rho
+                e[s0], e[s1] = swap16(e[s0], e[s1])
+    for k0 in range(8):
+        for rho in range(4):
+            e[4 * k0 + rho], e[4 * (k0 + 8) + rho] = swap32(e[4 * k0 + rho], e[4 * (k0 + 8) + rho])
+    out = np.zeros_like(p3)
+    for rho in range(4):
+        seq = np.stack([e[4 * k0 + rho] * np.conj(W(N, (lane + 64 * rho) * k0)) for k0 in range(16)])
+        a = np.fft.ifft(seq, axis=0) * 16                   # index n0
+        for n0 in range(16):
+            out[4 * n0 + rho] = a[n0]
+    y = np.zeros(N, dtype=np.complex128)
+    for row in range(64):
+        y[64 * row + lane] = out[row]
+    return y / N
+
+
+def main():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    p3 = forward(x)
+    ref = np.fft.fft(x)
+    got = np.zeros(N, dtype=np.complex128)
+    for slot in range(64):
+        got[k_of(slot, np.arange(64))] = p3[slot]
+    print("forward max err", np.max(np.abs(got - ref)))
+    y = inverse(p3)
+    print("roundtrip max err", np.max(np.abs(y - x)))
+    # overlap-save filtering check
+    h = rng.standard_normal(1023)
+    H = np.fft.fft(h, N)
+    Hp = np.zeros((64, 64), dtype=np.complex128)
+    for slot in range(64):
+        Hp[slot] = H[k_of(slot, np.arange(64))]
+    yb = inverse(p3 * Hp)
+    full = np.convolve(x, h)[:N]
+    print("overlap-save valid-part err", np.max(np.abs(yb[1022:] - full[1022:])))
+
+
+if __name__ == "__main__":
+    main()

@@ -10,7 +10,7 @@ import bench
 
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "fir255_dec4_2p28"
-    variants = [int(v) for v in sys.argv[2:]] or list(range(0, 7))
+    variants = [int(v) for v in sys.argv[2:]] or list(range(0, 7))   # variant 100 = overlap-save FFT backend
     taps_n, decim, log2n, _ = bench.WORKLOADS[wl]
     n = 1 << log2n
     fir = g.load_pkg().if_fir
@@ -25,7 +25,11 @@ def main():
         f.synth_device(x.data_ptr(), 0, n, 0)
         f.synchronize()
         for v in variants:
-            f.set_tuning(v)
+            if v == 100:
+                f.set_backend(fir.BACKEND_HIP_FFT)
+            else:
+                f.set_backend(fir.BACKEND_AUTO)
+                f.set_tuning(v)
             f.reset()
             y.zero_()
             torch.cuda.synchronize()
