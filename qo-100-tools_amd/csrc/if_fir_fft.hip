@@ -23,39 +23,75 @@
 namespace if_fir
 {
 
-struct cf
-{
-    float x, y;
-};
+// complex = one aligned VGPR pair (re, im): adds are single v_pk_add_f32, a complex multiply is v_pk_mul_f32 +
+// v_pk_fma_f32 with the swap/negate folded into op_sel / neg modifiers
+typedef float cf __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 typedef float f4v_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-// a * (wr + i*wi), or a * conj(w) when CONJ
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+
+// Complex multiply a * w (or a * conj(w)) in two packed instructions, swap/negate folded into VOP3P modifiers:
+//   t = a * (w.x, w.x);   d = (a.y, a.x) * (-+w.y, +-w.y) + t
 template <bool CONJ>
-__device__ __forceinline__ cf cmul(cf a, float wr, float wi)
+__device__ __forceinline__ cf cmul_v(cf a, cf w) // w in a VGPR pair (LDS tables)
 {
+    cf t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
     if (CONJ)
-        wi = -wi;
-    return {a.x * wr - a.y * wi, a.x * wi + a.y * wr};
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    return d;
 }
-// multiply by -j (forward) or +j (inverse)
-template <bool INV>
-__device__ __forceinline__ cf rot(cf a)
+template <bool CONJ>
+__device__ __forceinline__ cf cmul_s(cf a, cf w) // w wave-uniform (compile-time twiddle) in an SGPR pair
 {
-    return INV ? cf{-a.y, a.x} : cf{a.y, -a.x};
+    cf t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+    if (CONJ)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+    return d;
+}
+// a + w*b and a - w*b with w = -j (forward) or +j (inverse): one v_pk_add_f32 each
+template <bool INV>
+__device__ __forceinline__ cf add_rot(cf a, cf b)
+{
+    cf d;
+    if (INV) // (a.x - b.y, a.y + b.x)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    else     // (a.x + b.y, a.y - b.x)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <bool INV>
+__device__ __forceinline__ cf sub_rot(cf a, cf b)
+{
+    return add_rot<!INV>(a, b);
 }
 
 template <bool INV>
 __device__ __forceinline__ void bfly4(cf a, cf b, cf c, cf d, cf &u0, cf &u1, cf &u2, cf &u3)
 {
-    const cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = rot<INV>(csub(b, d));
-    u0 = cadd(t0, t2);
-    u1 = cadd(t1, t3);
-    u2 = csub(t0, t2);
-    u3 = csub(t1, t3);
+    const cf t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+    u0 = t0 + t2;
+    u1 = add_rot<INV>(t1, t3);
+    u2 = t0 - t2;
+    u3 = sub_rot<INV>(t1, t3);
+}
+// same with input c pre-multiplied by -j/+j (folded into the first adds)
+template <bool INV>
+__device__ __forceinline__ void bfly4_crot(cf a, cf b, cf c, cf d, cf &u0, cf &u1, cf &u2, cf &u3)
+{
+    const cf t0 = add_rot<INV>(a, c), t1 = sub_rot<INV>(a, c), t2 = b + d, t3 = b - d;
+    u0 = t0 + t2;
+    u1 = add_rot<INV>(t1, t3);
+    u2 = t0 - t2;
+    u3 = sub_rot<INV>(t1, t3);
 }
 
 // 16-point FFT, natural order in and out (radix-4 x radix-4 DIF; the digit reversal is register renaming)
@@ -67,19 +103,19 @@ __device__ __forceinline__ void fft16(cf (&v)[16])
 #pragma unroll
     for (int i = 0; i < 4; i++)
         bfly4<INV>(v[i], v[i + 4], v[i + 8], v[i + 12], y[0][i], y[1][i], y[2][i], y[3][i]);
-    // twiddles W16^(i*q), W16 = exp(-2*pi*j/16) (conjugated for the inverse)
-    y[1][1] = cmul<INV>(y[1][1], C1, -S1);
-    y[2][1] = cmul<INV>(y[2][1], R, -R);
-    y[3][1] = cmul<INV>(y[3][1], S1, -C1);
-    y[1][2] = cmul<INV>(y[1][2], R, -R);
-    y[2][2] = rot<INV>(y[2][2]);
-    y[3][2] = cmul<INV>(y[3][2], -R, -R);
-    y[1][3] = cmul<INV>(y[1][3], S1, -C1);
-    y[2][3] = cmul<INV>(y[2][3], -R, -R);
-    y[3][3] = cmul<INV>(y[3][3], -C1, S1);
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        bfly4<INV>(y[q][0], y[q][1], y[q][2], y[q][3], v[q], v[q + 4], v[q + 8], v[q + 12]);
+    // twiddles W16^(i*q), W16 = exp(-2*pi*j/16) (conjugated for the inverse); W16^4 = -j is folded into stage 2
+    y[1][1] = cmul_s<INV>(y[1][1], (cf){C1, -S1});
+    y[2][1] = cmul_s<INV>(y[2][1], (cf){R, -R});
+    y[3][1] = cmul_s<INV>(y[3][1], (cf){S1, -C1});
+    y[1][2] = cmul_s<INV>(y[1][2], (cf){R, -R});
+    y[3][2] = cmul_s<INV>(y[3][2], (cf){-R, -R});
+    y[1][3] = cmul_s<INV>(y[1][3], (cf){S1, -C1});
+    y[2][3] = cmul_s<INV>(y[2][3], (cf){-R, -R});
+    y[3][3] = cmul_s<INV>(y[3][3], (cf){-C1, S1});
+    bfly4<INV>(y[0][0], y[0][1], y[0][2], y[0][3], v[0], v[4], v[8], v[12]);
+    bfly4<INV>(y[1][0], y[1][1], y[1][2], y[1][3], v[1], v[5], v[9], v[13]);
+    bfly4_crot<INV>(y[2][0], y[2][1], y[2][2], y[2][3], v[2], v[6], v[10], v[14]);
+    bfly4<INV>(y[3][0], y[3][1], y[3][2], y[3][3], v[3], v[7], v[11], v[15]);
 }
 
 __device__ __forceinline__ void swap32(cf &vdst, cf &src)
@@ -108,14 +144,18 @@ __device__ __forceinline__ constexpr int phys(int i, int j)
 }
 
 constexpr int FFT_N = 4096;
-constexpr int XROW = 136;             // bytes per 16-entry row of the exchange-2 buffer (16*8 + 8 pad)
-constexpr int XBUF = 4 * 16 * XROW;   // per-wave exchange buffer
+constexpr int XROW = 136;             // bytes per 16-entry row of the exchange buffers (16*8 + 8 pad)
+constexpr int XREG = 16 * XROW + 32;  // one 16x16 region (+32 so that the 4 regions start on different banks)
+constexpr int XBUF = 4 * XREG;        // per-wave exchange buffer
 constexpr int FFT_WAVES = 8;
-constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_XB = 65536 + 2048;
+constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_TWD = 65536 + 2048, LDS_TWE = LDS_TWD + 8192,
+              LDS_XB = LDS_TWE + 8192;
+static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 constexpr int FFT_LDS_BYTES = LDS_XB + FFT_WAVES * XBUF;
 
 __device__ __forceinline__ void exchange1_fwd(cf (&r)[64])
 {
+    asm volatile("s_nop 1"); // inline-asm VALU write -> v_permlane read needs 2 wait states
 #pragma unroll
     for (int k0 = 0; k0 < 8; k0++)
 #pragma unroll
@@ -131,6 +171,7 @@ __device__ __forceinline__ void exchange1_fwd(cf (&r)[64])
 }
 __device__ __forceinline__ void exchange1_inv(cf (&r)[64])
 {
+    asm volatile("s_nop 1");
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -149,31 +190,76 @@ __device__ __forceinline__ void exchange1_inv(cf (&r)[64])
 __device__ __forceinline__ void exchange2(cf (&r)[64], char *xb, int lane)
 {
     const int g = lane >> 4, m = lane & 15;
-    char *wr = xb + g * (16 * XROW) + m * 8;      // + j*XROW : element (j, m)
-    const char *rd = xb + g * (16 * XROW) + m * XROW; // + j*8  : element (m, j)
+    char *wr = xb + g * XREG + m * 8;          // + j*XROW : element (j, m)
+    const char *rd = xb + g * XREG + m * XROW; // + j*8    : element (m, j)
 #pragma unroll
     for (int i = 0; i < 4; i++)
     {
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            *reinterpret_cast<f2v *>(wr + j * XROW) = (f2v){r[phys(i, j)].x, r[phys(i, j)].y};
+            *reinterpret_cast<f2v *>(wr + j * XROW) = r[phys(i, j)];
 #pragma unroll
         for (int j = 0; j < 16; j++)
         {
-            const f2v t = *reinterpret_cast<const f2v *>(rd + j * 8);
-            r[phys(i, j)] = {t.x, t.y};
+            r[phys(i, j)] = *reinterpret_cast<const f2v *>(rd + j * 8);
         }
     }
 }
 
-template <int OVL_ROWS>
+// decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
+// (4 x 16 x 16, tools/fft_model.py inverse_dec4) produces y[4m'] directly: lane = 4*mu1+mu2, slot mu0 -> y_D[64*mu0+lane]
+__device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], const f2v *twd, const f2v *twe, char *xb,
+                                             int lane)
+{
+    const int g = lane >> 4, m = lane & 15;
+    cf a[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        bfly4<true>(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3], a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+#pragma unroll
+        for (int mu2 = 1; mu2 < 4; mu2++)
+            a[4 * i + mu2] = cmul_v<true>(a[4 * i + mu2], twd[(i * 4 + mu2) * 64 + lane]);
+    }
+    // X: row transposition (one round of exchange 2): element j of lane (g, k1) -> lane (g, j), slot k1
+    {
+        char *wr = xb + g * XREG + m * 8;
+        const char *rd = xb + g * XREG + m * XROW;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            a[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+    }
+    fft16<true>(a); // over k1 -> mu1
+#pragma unroll
+    for (int mu1 = 1; mu1 < 16; mu1++)
+        a[mu1] = cmul_v<true>(a[mu1], twe[mu1 * 64 + lane]);
+    // Y: among the 16 lanes that share mu2: element mu1 of lane (k0, mu2) -> lane 4*mu1 + mu2, slot k0
+    {
+        const int k0 = 4 * g + (m >> 2), mu2 = m & 3;
+        char *wr = xb + mu2 * XREG + k0 * 8;                       // + mu1*XROW : element (mu1, k0) of region mu2
+        const char *rd = xb + (lane & 3) * XREG + (lane >> 2) * XROW; // + k0*8
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            c[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+    }
+    fft16<true>(c); // over k0 -> mu0
+}
+
+template <int OVL_ROWS, bool DEC4>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
-                                                        int T, int64_t N, int64_t nblocks, int32_t waves_total,
-                                                        unsigned int *queue)
+                                                        int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
+                                                        int32_t waves_total, unsigned int *queue)
 {
     constexpr int OVL = 64 * OVL_ROWS;
-    constexpr int L = FFT_N - OVL;
+    constexpr int L = FFT_N - OVL;         // new input samples per block
+    constexpr int LOUT = DEC4 ? L / 4 : L; // outputs per block
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -188,41 +274,50 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     const f2v *tw1 = reinterpret_cast<const f2v *>(smem + LDS_TW1);
     const f2v *hp = reinterpret_cast<const f2v *>(smem + LDS_HP);
     const f2v *tw2 = reinterpret_cast<const f2v *>(smem + LDS_TW2);
+    const f2v *twd = reinterpret_cast<const f2v *>(smem + LDS_TWD);
+    const f2v *twe = reinterpret_cast<const f2v *>(smem + LDS_TWE);
     char *xb = smem + LDS_XB + wid * XBUF;
+    (void)twd;
+    (void)twe;
 
     int64_t blk = (int64_t)blockIdx.x * FFT_WAVES + wid;
     unsigned int ticket = 0;
+    cf r[64];
+    bool loaded = false; // the rows of `blk` are already in flight (issued by the previous iteration's epilogue)
     while (blk < nblocks)
     {
         if (lane == 0)
-            ticket = atomicAdd(queue, 1u);   // next block for this wave, resolved at the end of the iteration
-        const int64_t s0 = blk * L - OVL;     // stream index of the block's first sample
-        cf r[64];
-        if (s0 >= 0 && s0 + FFT_N <= N)
+            ticket = atomicAdd(queue, 1u);   // next block for this wave, resolved in the epilogue
+        const int64_t s0 = blk * L - OVL + n0; // stream index of the block's first sample (n0: decimation phase)
+        if (!loaded)
         {
-            const f2v *src = in + s0 + lane;
-#pragma unroll
-            for (int row = 0; row < 64; row++)
+            if (s0 >= 0 && s0 + FFT_N <= N)
             {
-                const f2v t = src[row * 64];
-                r[row] = {t.x, t.y};
+                const f2v *src = in + s0 + lane;
+#pragma unroll
+                for (int rho = 0; rho < 4; rho++)
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                    {
+                        r[4 * j + rho] = src[(4 * j + rho) * 64];
+                    }
             }
-        }
-        else
-        {
-#pragma unroll
-            for (int row = 0; row < 64; row++)
+            else
             {
-                const int64_t gidx = s0 + row * 64 + lane;
-                f2v t = {0.f, 0.f};
-                if (gidx >= 0)
+#pragma unroll
+                for (int row = 0; row < 64; row++)
                 {
-                    if (gidx < N)
-                        t = in[gidx];
+                    const int64_t gidx = s0 + row * 64 + lane;
+                    f2v t = {0.f, 0.f};
+                    if (gidx >= 0)
+                    {
+                        if (gidx < N)
+                            t = in[gidx];
+                    }
+                    else if (gidx >= -(int64_t)(T - 1))
+                        t = hist[(T - 1) + gidx];
+                    r[row] = t;
                 }
-                else if (gidx >= -(int64_t)(T - 1))
-                    t = hist[(T - 1) + gidx];
-                r[row] = {t.x, t.y};
             }
         }
 
@@ -243,9 +338,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 else
                 {
                     const f2v w = tw1[(rho * 16 + j) * 64 + lane];
-                    r[4 * j + rho] = cmul<false>(t[j], w.x, w.y);
+                    r[4 * j + rho] = cmul_v<false>(t[j], w);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         exchange1_fwd(r);
 #pragma unroll
@@ -264,98 +360,149 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 else
                 {
                     const f2v w = tw2[j * 16 + (lane & 15)];
-                    r[phys(i, j)] = cmul<false>(t[j], w.x, w.y);
+                    r[phys(i, j)] = cmul_v<false>(t[j], w);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         exchange2(r, xb, lane);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
+        const int64_t blk_next = (int64_t)waves_total + (int64_t)__builtin_amdgcn_readfirstlane(ticket);
+        const int64_t s0n = blk_next * L - OVL + n0;
+        const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && (s0n + FFT_N <= N);
+        const f2v *nsrc = in + s0n + lane;
+        const int64_t o0 = blk * LOUT + lane;
+        const bool full = (blk * LOUT + LOUT <= M);
+        if constexpr (DEC4)
         {
-            cf t[16];
+            // ---- pass 3, multiply by H/4096, fold the 4 aliases: z(i, k2') = sum_j Y(i, k2' + 4j) ------------------
+            cf z[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                t[j] = r[phys(i, j)];
-            fft16<false>(t);
-            // ---- pointwise multiply by H/4096 and start the inverse (pass 3^-1) in the same registers -----------
-#pragma unroll
-            for (int j = 0; j < 16; j++)
+            for (int i = 0; i < 4; i++)
             {
-                const f2v h = hp[(i * 16 + j) * 64 + lane];
-                t[j] = cmul<false>(t[j], h.x, h.y);
-            }
-            fft16<true>(t);
+                cf t[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                r[phys(i, j)] = t[j];
-        }
-        exchange2(r, xb, lane);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-        {
-            cf t[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++)
-            {
-                if (j == 0)
+                for (int j = 0; j < 16; j++)
                     t[j] = r[phys(i, j)];
-                else
-                {
-                    const f2v w = tw2[j * 16 + (lane & 15)];
-                    t[j] = cmul<true>(r[phys(i, j)], w.x, w.y);
-                }
+                fft16<false>(t);
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    t[j] = cmul_v<false>(t[j], hp[(i * 16 + j) * 64 + lane]);
+#pragma unroll
+                for (int k2p = 0; k2p < 4; k2p++)
+                    z[4 * i + k2p] = (t[k2p] + t[k2p + 4]) + (t[k2p + 8] + t[k2p + 12]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            fft16<true>(t);
-#pragma unroll
-            for (int j = 0; j < 16; j++)
-                r[phys(i, j)] = t[j];
-        }
-        exchange1_inv(r);
-#pragma unroll
-        for (int rho = 0; rho < 4; rho++)
-        {
-            cf t[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++)
+            // the 64 data registers are dead: start the next block's loads now (they fly under the small inverse)
+            if (next_fast)
             {
-                if (j == 0)
-                    t[j] = r[4 * j + rho];
-                else
-                {
-                    const f2v w = tw1[(rho * 16 + j) * 64 + lane];
-                    t[j] = cmul<true>(r[4 * j + rho], w.x, w.y);
-                }
+#pragma unroll
+                for (int rho = 0; rho < 4; rho++)
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        r[4 * j + rho] = nsrc[(4 * j + rho) * 64];
             }
-            fft16<true>(t);
+            cf c[16];
+            inverse_dec4(z, c, twd, twe, xb, lane);
+            constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
+            if (full)
+            {
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                r[4 * j + rho] = t[j];
-        }
-
-        // ---- store the valid part --------------------------------------------------------------------------------
-        const int64_t o0 = blk * L + lane;
-        if (blk * L + L <= N)
-        {
+                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    out[o0 + (mu0 - MU0_FIRST) * 64] = c[mu0];
+            }
+            else
+            {
 #pragma unroll
-            for (int row = OVL_ROWS; row < 64; row++)
-                out[o0 + (row - OVL_ROWS) * 64] = (f2v){r[row].x, r[row].y};
+                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    if (o0 + (mu0 - MU0_FIRST) * 64 < M)
+                        out[o0 + (mu0 - MU0_FIRST) * 64] = c[mu0];
+            }
         }
         else
         {
 #pragma unroll
-            for (int row = OVL_ROWS; row < 64; row++)
-                if (o0 + (row - OVL_ROWS) * 64 < N)
-                    out[o0 + (row - OVL_ROWS) * 64] = (f2v){r[row].x, r[row].y};
+            for (int i = 0; i < 4; i++)
+            {
+                cf t[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    t[j] = r[phys(i, j)];
+                fft16<false>(t);
+                // ---- pointwise multiply by H/4096 and start the inverse (pass 3^-1) in the same registers -------
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    t[j] = cmul_v<false>(t[j], hp[(i * 16 + j) * 64 + lane]);
+                fft16<true>(t);
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    r[phys(i, j)] = t[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            exchange2(r, xb, lane);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                cf t[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                {
+                    if (j == 0)
+                        t[j] = r[phys(i, j)];
+                    else
+                        t[j] = cmul_v<true>(r[phys(i, j)], tw2[j * 16 + (lane & 15)]);
+                }
+                fft16<true>(t);
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    r[phys(i, j)] = t[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            exchange1_inv(r);
+            // ---- last inverse pass, group by group: finish 16 rows, store them, and refill the same registers with
+            //      the next block's rows (the loads fly while the remaining groups and the next forward pass compute)
+#pragma unroll
+            for (int rho = 0; rho < 4; rho++)
+            {
+                cf t[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                {
+                    if (j == 0)
+                        t[j] = r[4 * j + rho];
+                    else
+                        t[j] = cmul_v<true>(r[4 * j + rho], tw1[(rho * 16 + j) * 64 + lane]);
+                }
+                fft16<true>(t);
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                {
+                    const int row = 4 * j + rho;
+                    if (row >= OVL_ROWS)
+                    {
+                        if (full || o0 + (int64_t)(row - OVL_ROWS) * 64 < M)
+                            out[o0 + (row - OVL_ROWS) * 64] = t[j];
+                    }
+                }
+                if (next_fast)
+                {
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        r[4 * j + rho] = nsrc[(4 * j + rho) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        blk = (int64_t)waves_total + (int64_t)__builtin_amdgcn_readfirstlane(ticket);
+        loaded = next_fast;
+        blk = blk_next;
     }
 }
 
-template <int OVL_ROWS>
+template <int OVL_ROWS, bool DEC4>
 static hipError_t launch_fft_t(const LaunchArgs &a)
 {
-    auto kern = fir_fft_kernel<OVL_ROWS>;
+    auto kern = fir_fft_kernel<OVL_ROWS, DEC4>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
+    constexpr int LOUT = DEC4 ? L / 4 : L;
     static bool attr_done[16] = {false};
     static int cus[16] = {0};
     const int dev = a.device & 15;
@@ -372,7 +519,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
         cus[dev] = prop.multiProcessorCount;
         attr_done[dev] = true;
     }
-    const int64_t nblocks = (a.N + L - 1) / L;
+    const int64_t nblocks = (a.M + LOUT - 1) / LOUT;
     if (nblocks <= 0)
         return hipSuccess;
     int64_t wgs = cus[dev];
@@ -384,13 +531,13 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), FFT_LDS_BYTES, a.stream,
                        reinterpret_cast<const f2v *>(a.in), reinterpret_cast<f2v *>(a.out),
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist), a.T, a.N,
-                       nblocks, (int32_t)(wgs * FFT_WAVES), (unsigned int *)a.queue);
+                       a.n0, a.M, nblocks, (int32_t)(wgs * FFT_WAVES), (unsigned int *)a.queue);
     return hipGetLastError();
 }
 
 bool fft_supported(int T, int D)
 {
-    return D == 1 && T >= 1 && T <= 1025;
+    return (D == 1 || D == 4) && T >= 1 && T <= 1025;
 }
 
 int fft_overlap_rows(int T)
@@ -402,17 +549,41 @@ hipError_t launch_fft(const LaunchArgs &a)
 {
     if (!fft_supported(a.T, a.D) || !a.fft_tables)
         return hipErrorInvalidConfiguration;
-    return fft_overlap_rows(a.T) == 4 ? launch_fft_t<4>(a) : launch_fft_t<16>(a);
+    const bool small = fft_overlap_rows(a.T) == 4;
+    if (a.D == 4)
+        return small ? launch_fft_t<4, true>(a) : launch_fft_t<16, true>(a);
+    return small ? launch_fft_t<4, false>(a) : launch_fft_t<16, false>(a);
 }
 
 // Host side: twiddle and H tables in the kernel's LDS image order (float64 math, rounded once to float32).
 //   [0, 32 KB)      tw1[(rho*16+k0)*64 + lane] = W4096^((lane+64*rho)*k0)
 //   [32 KB, 64 KB)  hp [(i*16+k2)*64 + lane]   = FFT(taps)[(4*(lane/16)+i) + 16*(lane%16) + 256*k2] / 4096
 //   [64 KB, 66 KB)  tw2[k1*16 + n2]            = W256^(n2*k1)
+//   [66 KB, 82 KB)  twd, twe: twiddles of the decimate-by-4 1024-point inverse
 void fft_build_tables(const float *taps, int T, float *tables /* FFT_TABLE_FLOATS floats */)
 {
     const double PI2 = 6.283185307179586476925286766559;
     float *tw1 = tables, *hp = tables + 2 * 4096, *tw2 = tables + 4 * 4096;
+    float *twd = tw2 + 2 * 256, *twe = twd + 2 * 1024;
+    // decimate-by-4 inverse: twd[(i*4+mu2)*64 + lane] = W1024^((16*(lane%16) + 4*(lane/16) + i)*mu2)
+    //                        twe[mu1*64 + lane]       = W256^((4*(lane/16) + (lane%16)/4)*mu1)
+    for (int i = 0; i < 4; i++)
+        for (int mu2 = 0; mu2 < 4; mu2++)
+            for (int lane = 0; lane < 64; lane++)
+            {
+                const int e = ((16 * (lane % 16) + 4 * (lane / 16) + i) * mu2) % 1024;
+                const double a = -PI2 * (double)e / 1024.0;
+                twd[2 * ((i * 4 + mu2) * 64 + lane) + 0] = (float)cos(a);
+                twd[2 * ((i * 4 + mu2) * 64 + lane) + 1] = (float)sin(a);
+            }
+    for (int mu1 = 0; mu1 < 16; mu1++)
+        for (int lane = 0; lane < 64; lane++)
+        {
+            const int e = ((4 * (lane / 16) + (lane % 16) / 4) * mu1) % 256;
+            const double a = -PI2 * (double)e / 256.0;
+            twe[2 * (mu1 * 64 + lane) + 0] = (float)cos(a);
+            twe[2 * (mu1 * 64 + lane) + 1] = (float)sin(a);
+        }
     for (int rho = 0; rho < 4; rho++)
         for (int k0 = 0; k0 < 16; k0++)
             for (int lane = 0; lane < 64; lane++)

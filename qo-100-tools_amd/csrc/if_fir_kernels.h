@@ -36,7 +36,7 @@ struct LaunchArgs
 bool direct_supported(int T, int D);
 hipError_t launch_fir(const LaunchArgs &a, int variant);
 // overlap-save FFT backend (if_fir_fft.hip)
-constexpr int FFT_TABLE_FLOATS = 2 * 4096 * 2 + 2 * 256;
+constexpr int FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024);
 bool fft_supported(int T, int D);
 hipError_t launch_fft(const LaunchArgs &a);
 void fft_build_tables(const float *taps, int T, float *tables);

@@ -77,7 +77,7 @@ def test_generic_backend_forced_equals_direct(fir, oracle):
         b = f.process(x)
         assert np.array_equal(a, b)
         with pytest.raises(fir.IfFirError):
-            f.set_backend(fir.BACKEND_HIP_FFT)   # not built this round: must say so, context stays usable
+            f.set_backend(fir.BACKEND_HIP_TAPSPLIT)   # not built this round: must say so, context stays usable
         f.reset()
         assert np.array_equal(f.process(x), b)
 
@@ -237,9 +237,43 @@ def test_fft_backend_block_edges(fir, oracle, n):
 
 
 def test_fft_backend_rejects_unsupported(fir):
-    with fir.IfFir(fir.bpf_design(255), 4, 1000) as f:
+    with fir.IfFir(fir.bpf_design(255), 3, 1000) as f:
         with pytest.raises(fir.IfFirError):
-            f.set_backend(fir.BACKEND_HIP_FFT)        # decimating overlap-save is not built
+            f.set_backend(fir.BACKEND_HIP_FFT)        # only D = 1 and D = 4 are built
     with fir.IfFir(fir.bpf_design(2047), 1, 1000) as f:
         with pytest.raises(fir.IfFirError):
             f.set_backend(fir.BACKEND_HIP_FFT)        # taps beyond the 4096-point block's overlap
+
+
+@pytest.mark.parametrize("t", [255, 127, 1023, 257])
+def test_fft_backend_decimate4_vs_oracle(fir, oracle, t):
+    """Overlap-save with the decimation folded into the frequency domain (1024-point inverse): SPEC tolerance against
+    the float64 oracle, one-shot and in ragged pieces (odd piece lengths exercise every decimation phase n0)."""
+    rng = np.random.default_rng(40 + t)
+    taps = fir.bpf_design(t)
+    n = 60_013
+    x = np.concatenate([oracle.synth_iq(n // 2, 9), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
+    ref = oracle.fir_f64(taps, x, 4)
+    with fir.IfFir(taps, 4, n) as f:
+        f.set_backend(fir.BACKEND_HIP_FFT)
+        y = f.process(x)
+        assert y.shape == ref.shape
+        l2, mx = oracle.err_metrics(y, ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        f.reset()
+        cuts = [0, 1, 2, 3, 7, 500, 1021, 3841, 3840 * 2 + 6, 20_001, 40_003, n]
+        parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 959 * 4, 960 * 4, 960 * 4 + 1, 3841, 4096, 7681, 15361])
+def test_fft_backend_decimate4_block_edges(fir, oracle, n):
+    taps = fir.bpf_design(255)
+    x = oracle.synth_iq(n, 8)
+    with fir.IfFir(taps, 4, n) as f:
+        f.set_backend(fir.BACKEND_HIP_FFT)
+        y = f.process(x)
+    ref = oracle.fir_f64(taps, x, 4)
+    assert y.shape == ref.shape
+    assert np.max(np.abs(y - ref)) <= 1e-6 * max(np.max(np.abs(ref)), 0.5), (n, np.max(np.abs(y - ref)))

@@ -150,3 +150,60 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# decimate-by-4 variant: fold the 4 aliases in the frequency domain (in-lane) and run a 1024-point inverse
+#   k' = k0 + 16*k1 + 256*k2'   (k0 = 4g+i, k1 = lane%16, k2' in 0..3)      m' = 64*mu0 + 4*mu1 + mu2
+#   A: 4-point iDFT over k2' -> slot (i, mu2); twiddle conj W1024^((16*k1 + k0)*mu2)
+#   X: row transposition: element j=4i+mu2 of lane (g,k1) -> lane (g,j), slot k1
+#   B: iFFT16 over k1 -> mu1; twiddle conj W256^(k0*mu1), k0 = 4g + (lane%16)//4
+#   Y: transposition among the 16 lanes sharing mu2: element mu1 of lane (k0, mu2) -> lane 4*mu1+mu2, slot k0
+#   C: iFFT16 over k0 -> mu0.   result: lane = 4*mu1+mu2, slot mu0:  y_D[64*mu0 + lane]
+def inverse_dec4(p3):
+    lane = np.arange(64)
+    g, m = lane // 16, lane % 16
+    z = np.zeros((16, 64), dtype=np.complex128)          # slot (i, k2') := 4*i + k2'
+    for i in range(4):
+        for k2p in range(4):
+            z[4 * i + k2p] = sum(p3[16 * i + k2p + 4 * j] for j in range(4))
+    a = np.zeros_like(z)                                  # slot j = 4*i + mu2
+    for i in range(4):
+        seq = np.fft.ifft(z[4 * i:4 * i + 4], axis=0) * 4
+        for mu2 in range(4):
+            a[4 * i + mu2] = seq[mu2] * np.conj(W(1024, (16 * m + 4 * g + i) * mu2))
+    x = np.zeros_like(a)                                  # lane (g, j), slot k1
+    for gg in range(4):
+        x[:, 16 * gg:16 * gg + 16] = a[:, 16 * gg:16 * gg + 16].T
+    j = lane % 16
+    i_l, mu2_l = j // 4, j % 4
+    k0_l = 4 * g + i_l
+    b = np.fft.ifft(x, axis=0) * 16                       # slot mu1
+    for mu1 in range(16):
+        b[mu1] = b[mu1] * np.conj(W(256, k0_l * mu1))
+    y = np.zeros_like(b)                                  # lane 4*mu1+mu2, slot k0
+    for src_lane in range(64):
+        for mu1 in range(16):
+            y[k0_l[src_lane], 4 * mu1 + mu2_l[src_lane]] = b[mu1, src_lane]
+    c = np.fft.ifft(y, axis=0) * 16                       # slot mu0
+    out = np.zeros(1024, dtype=np.complex128)
+    for mu0 in range(16):
+        out[64 * mu0 + lane] = c[mu0]
+    return out / N
+
+
+def main_dec4():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    h = rng.standard_normal(255)
+    H = np.fft.fft(h, N)
+    Hp = np.zeros((64, 64), dtype=np.complex128)
+    for slot in range(64):
+        Hp[slot] = H[k_of(slot, np.arange(64))]
+    yd = inverse_dec4(forward(x) * Hp)
+    full = np.convolve(x, h)[:N]
+    print("dec4 valid-part err", np.max(np.abs(yd[64:] - full[256::4])))
+
+
+if __name__ == "__main__":
+    main_dec4()
