@@ -206,6 +206,58 @@ __device__ __forceinline__ void exchange2(cf (&r)[64], char *xb, int lane)
     }
 }
 
+// ---- memory helpers --------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t srd_t;
+typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2_t;
+
+// buffer descriptor over [p, p + bytes): wave-uniform by construction (readfirstlane) so that hipcc emits plain
+// buffer_load/store with the descriptor in SGPRs (no waterfall loop); out-of-range lanes read 0 / are not written
+__device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
+{
+    const uint64_t a = (uint64_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int64_t clipped = bytes < 0 ? 0 : (bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes);
+    const unsigned n = __builtin_amdgcn_readfirstlane((unsigned)clipped);
+    void *q = (void *)(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
+}
+__device__ __forceinline__ cf buf_load(srd_t rsrc, unsigned voff, unsigned soff)
+{
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+    return (cf){__uint_as_float(v[0]), __uint_as_float(v[1])};
+}
+__device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned soff, cf d)
+{
+    u32x2_t v;
+    v[0] = __float_as_uint(d.x);
+    v[1] = __float_as_uint(d.y);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, 0);
+}
+
+// one returning atomic add issued by lane 0 only, WITHOUT the wait hipcc would put right behind it (that wait is a
+// vmcnt(0): it would drain the prefetched rows of the next block); the caller waits with queue_ticket_wait() where
+// nothing younger is in flight
+__device__ __forceinline__ unsigned queue_ticket_issue(unsigned int *queue)
+{
+    unsigned t;
+    unsigned long long save;
+    const unsigned one = 1u;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_add %0, %2, %3, off sc0\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(t), "=&s"(save)
+                 : "v"(queue), "v"(one)
+                 : "memory");
+    return t;
+}
+__device__ __forceinline__ unsigned queue_ticket_wait(unsigned t)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)::"memory");
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
 // decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
 // (4 x 16 x 16, tools/fft_model.py inverse_dec4) produces y[4m'] directly: lane = 4*mu1+mu2, slot mu0 -> y_D[64*mu0+lane]
 __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], const f2v *twd, const f2v *twe, char *xb,
@@ -255,11 +307,14 @@ template <int OVL_ROWS, bool DEC4>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
-                                                        int32_t waves_total, unsigned int *queue)
+                                                        int32_t waves_total, int32_t RUN, unsigned int *queue, unsigned long long *dbg,
+                                                        int32_t diag)
 {
+    // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int L = FFT_N - OVL;         // new input samples per block
     constexpr int LOUT = DEC4 ? L / 4 : L; // outputs per block
+    constexpr int EARLY_GROUPS = 3;        // dec4: batches of next-block loads issued during pass 3
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -280,47 +335,71 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     (void)twd;
     (void)twe;
 
-    int64_t blk = (int64_t)blockIdx.x * FFT_WAVES + wid;
+    // diagnostics (only with a debug buffer): phase stamps of the first 32 iterations of a few waves
+    int dbg_it = 0;
+    const bool dbg_on = dbg && ((blockIdx.x & 63) == 0) && (wid < 2);
+    (void)dbg_it;
+    (void)dbg_on;
+#ifdef IF_FIR_FFT_STAMPS
+#define FFT_STAMP(slot)                                                                                          \
+    do                                                                                                           \
+    {                                                                                                            \
+        if (dbg_on && dbg_it < 32 && lane == 0)                                                                  \
+            dbg[(((blockIdx.x >> 6) * 2 + wid) * 32 + dbg_it) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+    } while (0)
+#else
+#define FFT_STAMP(slot) (void)0
+#endif
+    // Work distribution: run q = blocks [q*RUN, (q+1)*RUN).  Wave w starts with run w; further runs come from one
+    // atomic counter, reserved a whole run ahead.  (One ticket per BLOCK saturates the counter: a single address takes
+    // ~88 atomics/us, 70k blocks would cost 0.8 ms by themselves.)
+    int64_t blk = ((int64_t)blockIdx.x * FFT_WAVES + wid) * RUN;
+    int64_t blk_end = blk + RUN < nblocks ? blk + RUN : nblocks;
     unsigned int ticket = 0;
+    bool ticket_pending = false;
     cf r[64];
     bool loaded = false; // the rows of `blk` are already in flight (issued by the previous iteration's epilogue)
+    const unsigned voff = (unsigned)lane * 8u;
     while (blk < nblocks)
     {
-        if (lane == 0)
-            ticket = atomicAdd(queue, 1u);   // next block for this wave, resolved in the epilogue
-        const int64_t s0 = blk * L - OVL + n0; // stream index of the block's first sample (n0: decimation phase)
-        if (!loaded)
+        FFT_STAMP(0);
+        if (!ticket_pending)
         {
-            if (s0 >= 0 && s0 + FFT_N <= N)
+            ticket = queue_ticket_issue(queue); // next run for this wave, resolved at the last block of this run
+            ticket_pending = true;
+        }
+        const int64_t s0 = blk * L - OVL + n0; // stream index of the block's first sample (n0: decimation phase)
+        if (!loaded && !(diag & 1))
+        {
+            if (s0 >= 0)
             {
-                const f2v *src = in + s0 + lane;
+                // rows beyond the end of the input read 0 through the descriptor's bounds check
+                const srd_t srd = make_srd(in + s0, (N - s0) * 8);
 #pragma unroll
                 for (int rho = 0; rho < 4; rho++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                    {
-                        r[4 * j + rho] = src[(4 * j + rho) * 64];
-                    }
+                        r[4 * j + rho] = buf_load(srd, voff, (4 * j + rho) * 512);
             }
             else
             {
+                // first block of a call: negative stream indices come from the history (or are zero); one of the two
+                // loads of every element is out of range and returns 0
+                const srd_t srd_in = make_srd(in, N * 8);
+                const srd_t srd_h = make_srd(hist, (int64_t)(T - 1) * 8);
 #pragma unroll
                 for (int row = 0; row < 64; row++)
                 {
                     const int64_t gidx = s0 + row * 64 + lane;
-                    f2v t = {0.f, 0.f};
-                    if (gidx >= 0)
-                    {
-                        if (gidx < N)
-                            t = in[gidx];
-                    }
-                    else if (gidx >= -(int64_t)(T - 1))
-                        t = hist[(T - 1) + gidx];
-                    r[row] = t;
+                    const int64_t hidx = gidx + (T - 1);
+                    const unsigned oi = (gidx >= 0) ? (unsigned)gidx * 8u : 0x80000000u;
+                    const unsigned oh = (gidx < 0 && hidx >= 0) ? (unsigned)hidx * 8u : 0x80000000u;
+                    r[row] = buf_load(srd_in, oi, 0) + buf_load(srd_h, oh, 0);
                 }
             }
         }
 
+        FFT_STAMP(1);
         // ---- forward ------------------------------------------------------------------------------------------
 #pragma unroll
         for (int rho = 0; rho < 4; rho++)
@@ -343,6 +422,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        FFT_STAMP(2);
         exchange1_fwd(r);
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -365,13 +445,22 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        FFT_STAMP(3);
         exchange2(r, xb, lane);
-        const int64_t blk_next = (int64_t)waves_total + (int64_t)__builtin_amdgcn_readfirstlane(ticket);
+        FFT_STAMP(4);
+        int64_t blk_next = blk + 1;
+        if (blk_next >= blk_end)
+        {
+            blk_next = ((int64_t)waves_total + (int64_t)queue_ticket_wait(ticket)) * RUN;
+            blk_end = blk_next + RUN < nblocks ? blk_next + RUN : nblocks;
+            ticket_pending = false;
+        }
         const int64_t s0n = blk_next * L - OVL + n0;
-        const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && (s0n + FFT_N <= N);
-        const f2v *nsrc = in + s0n + lane;
-        const int64_t o0 = blk * LOUT + lane;
-        const bool full = (blk * LOUT + LOUT <= M);
+        const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
+        const srd_t nsrd = make_srd(in + (next_fast ? s0n : 0), next_fast ? (N - s0n) * 8 : 0);
+        // outputs beyond M are dropped by the descriptor's bounds check
+        const int64_t obase = blk * LOUT;
+        const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
         if constexpr (DEC4)
         {
             // ---- pass 3, multiply by H/4096, fold the 4 aliases: z(i, k2') = sum_j Y(i, k2' + 4j) ------------------
@@ -390,33 +479,34 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                 for (int k2p = 0; k2p < 4; k2p++)
                     z[4 * i + k2p] = (t[k2p] + t[k2p + 4]) + (t[k2p + 8] + t[k2p + 12]);
+                // the 16 registers of this group are dead: refill them with rows of the next block right away, so the
+                // loads have the rest of pass 3 and the whole small inverse to land (EARLY_GROUPS of the 4 batches;
+                // the last ones are issued after the inverse to keep its temporaries out of scratch)
+                if (i < EARLY_GROUPS && next_fast)
+                {
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        r[phys(i, j)] = buf_load(nsrd, voff, phys(i, j) * 512);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // the 64 data registers are dead: start the next block's loads now (they fly under the small inverse)
+            FFT_STAMP(5);
+            cf c[16];
+            inverse_dec4(z, c, twd, twe, xb, lane);
+            __builtin_amdgcn_sched_barrier(0);
             if (next_fast)
             {
 #pragma unroll
-                for (int rho = 0; rho < 4; rho++)
+                for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        r[4 * j + rho] = nsrc[(4 * j + rho) * 64];
+                        r[phys(i, j)] = buf_load(nsrd, voff, phys(i, j) * 512);
             }
-            cf c[16];
-            inverse_dec4(z, c, twd, twe, xb, lane);
+            FFT_STAMP(6);
             constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
-            if (full)
-            {
 #pragma unroll
-                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                    out[o0 + (mu0 - MU0_FIRST) * 64] = c[mu0];
-            }
-            else
-            {
-#pragma unroll
-                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                    if (o0 + (mu0 - MU0_FIRST) * 64 < M)
-                        out[o0 + (mu0 - MU0_FIRST) * 64] = c[mu0];
-            }
+            for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                buf_store(osrd, voff, (mu0 - MU0_FIRST) * 512, c[mu0]);
         }
         else
         {
@@ -478,20 +568,19 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
                     const int row = 4 * j + rho;
                     if (row >= OVL_ROWS)
-                    {
-                        if (full || o0 + (int64_t)(row - OVL_ROWS) * 64 < M)
-                            out[o0 + (row - OVL_ROWS) * 64] = t[j];
-                    }
+                        buf_store(osrd, voff, (row - OVL_ROWS) * 512, t[j]);
                 }
                 if (next_fast)
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        r[4 * j + rho] = nsrc[(4 * j + rho) * 64];
+                        r[4 * j + rho] = buf_load(nsrd, voff, (4 * j + rho) * 512);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        FFT_STAMP(7);
+        dbg_it++;
         loaded = next_fast;
         blk = blk_next;
     }
@@ -522,16 +611,22 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     const int64_t nblocks = (a.M + LOUT - 1) / LOUT;
     if (nblocks <= 0)
         return hipSuccess;
+    // blocks per queue ticket: long enough to keep the counter far from saturation (~88 tickets/us), short enough that
+    // the last runs do not leave waves idle (at least ~6 runs per wave)
+    int64_t run = nblocks / ((int64_t)cus[dev] * FFT_WAVES * 6);
+    run = run < 1 ? 1 : (run > 8 ? 8 : run);
+    const int64_t nruns = (nblocks + run - 1) / run;
     int64_t wgs = cus[dev];
-    if (wgs * FFT_WAVES > nblocks)
-        wgs = (nblocks + FFT_WAVES - 1) / FFT_WAVES;
+    if (wgs * FFT_WAVES > nruns)
+        wgs = (nruns + FFT_WAVES - 1) / FFT_WAVES;
     hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), FFT_LDS_BYTES, a.stream,
                        reinterpret_cast<const f2v *>(a.in), reinterpret_cast<f2v *>(a.out),
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist), a.T, a.N,
-                       a.n0, a.M, nblocks, (int32_t)(wgs * FFT_WAVES), (unsigned int *)a.queue);
+                       a.n0, a.M, nblocks, (int32_t)(wgs * FFT_WAVES), (int32_t)run, (unsigned int *)a.queue,
+                       (unsigned long long *)a.dbg, (int32_t)a.diag);
     return hipGetLastError();
 }
 

@@ -359,6 +359,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.fft_tables = ctx->d_fft_tables;
     a.queue = ctx->d_queue;
     a.dbg = ctx->d_dbg;
+    a.diag = (ctx->backend == IF_FIR_BACKEND_HIP_FFT && ctx->variant >= 1000) ? ctx->variant - 1000 : 0;
     if (ctx->backend == IF_FIR_BACKEND_HIP_FFT)
         HIP_TRY(ctx, if_fir::launch_fft(a));
     else

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""fft_stamps.py — phase timing of the overlap-save kernel's wave loop (development tool)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import __graft_entry__ as g  # noqa: E402
+import bench  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "fir255_dec4_2p28"
+taps_n, decim, log2n, _ = bench.WORKLOADS[wl]
+n = 1 << log2n
+fir = g.load_pkg().if_fir
+torch.cuda.set_device(0)
+x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+with fir.IfFir(fir.bpf_design(taps_n), decim, 0) as f:
+    f.set_backend(fir.BACKEND_HIP_FFT)
+    y = torch.empty(2 * f.out_count(n), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    f.synth_device(x.data_ptr(), 0, n, 0)
+    f.synchronize()
+    f.debug_stamps()
+    for _ in range(3):
+        f.process_device(x.data_ptr(), y.data_ptr(), n)
+    f.synchronize()
+    s = f.debug_stamps(2048).astype(np.int64).reshape(-1)[:8 * 32 * 8].reshape(8, 32, 8)
+    names = ["top->loaded", "pass1", "exch1+pass2", "exch2", "pass3(+fold,issue)", "inverse", "stores"]
+    print(wl)
+    for w in range(4):
+        d = np.diff(s[w], axis=1) * 0.01   # us
+        tot = (s[w][:, 7] - s[w][:, 0]) * 0.01
+        ok = s[w][:, 7] > 0
+        if not ok.any():
+            continue
+        print("wave", w, "iterations", ok.sum(), "mean us per phase:",
+              " ".join("%s=%.2f" % (nm, v) for nm, v in zip(names, d[ok].mean(axis=0))), "total=%.2f" % tot[ok].mean())
+        gaps = (s[w][1:, 0] - s[w][:-1, 7]) * 0.01
+        print("   loop-back gap us: %.2f ; per-iteration totals: %s" %
+              (gaps[ok[1:]].mean(), " ".join("%.1f" % v for v in tot[ok][:12])))

@@ -25,8 +25,9 @@ def main():
         f.synth_device(x.data_ptr(), 0, n, 0)
         f.synchronize()
         for v in variants:
-            if v == 100:
+            if v >= 100:
                 f.set_backend(fir.BACKEND_HIP_FFT)
+                f.set_tuning(v if v >= 1000 else 0)   # 1001/1002/1003: FFT diagnostics (skip loads / stores / both)
             else:
                 f.set_backend(fir.BACKEND_AUTO)
                 f.set_tuning(v)
