@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="fir255_dec4_2p28", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (if_fir_set_tuning)")
+    ap.add_argument("--backend", default="auto", choices=["auto", "direct", "fft", "generic"],
+                    help="kernel family (auto = library default: overlap-save FFT where it applies)")
     ap.add_argument("--scatter", action="store_true", help="also time RCCL scatter/gather of channels from rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -118,7 +120,9 @@ def main():
     taps_n, decim, log2n, desc = WORKLOADS[args.workload]
     n = 1 << log2n
     taps = fir.bpf_design(taps_n)
-    f = fir.IfFir(taps, decim, 0, device=local_rank)
+    backend_ids = {"auto": fir.BACKEND_AUTO, "direct": fir.BACKEND_HIP_DIRECT, "fft": fir.BACKEND_HIP_FFT,
+                   "generic": fir.BACKEND_HIP_GENERIC}
+    f = fir.IfFir(taps, decim, 0, device=local_rank, backend=backend_ids[args.backend])
     if args.variant is not None:
         f.set_tuning(args.variant)
     stream = torch.cuda.Stream(device=dev)   # a real (non-null) HIP stream: handle 0 would mean "context's own stream"
@@ -160,6 +164,30 @@ def main():
     wall_max, dev_ms_max = float(t[0].item()), float(t[1].item())
 
     extra = {}
+    names = {1: "hip_direct", 2: "hip_tapsplit", 3: "hip_generic", 4: "hip_fft"}
+    if rank == 0 and args.backend == "auto" and f.get_backend() == fir.BACKEND_HIP_FFT and taps_n in (127, 255) \
+            and decim in (1, 4):
+        # the north_star's direct-form MAC kernel, timed beside the default overlap-save path (same buffers, same
+        # stream; not part of `value`)
+        f.set_backend(fir.BACKEND_HIP_DIRECT)
+        f.reset()
+        for _ in range(args.warmup):
+            step_stream()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            step_stream()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        dms = e0.elapsed_time(e1) / args.steps
+        extra["direct_form"] = {
+            "backend": "hip_direct", "kernel_ms": round(dms, 4), "msamples_per_s": round(n / dms / 1e3, 1),
+            "hbm_frac": round(algorithmic_bytes_per_sample(decim) * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "valu_tflops": round(algorithmic_flops_per_sample(taps_n, decim) * n / (dms * 1e-3) / 1e12, 2),
+            "note": "hand-written v_pk_fma_f32 direct form (bit-exact vs the oracle's float32 order model); power-limited"}
+        f.set_backend(fir.BACKEND_AUTO)
+        f.reset()
     if args.scatter and world > 1:
         cs = pkg.channel_shard
         root_inputs = None
@@ -209,7 +237,7 @@ def main():
         # the stream was continued for warmup+steps calls, so regenerate the expected state cheaply: only check that
         # a fresh context reproduces the oracle on the head of the stream.
         oracle = graft.load_oracle()
-        f2 = fir.IfFir(taps, decim, 0, device=local_rank)
+        f2 = fir.IfFir(taps, decim, 0, device=local_rank, backend=backend_ids[args.backend])
         f2.set_stream(stream.cuda_stream)
         if args.variant is not None:
             f2.set_tuning(args.variant)
@@ -218,10 +246,12 @@ def main():
         f2.process_device(x.data_ptr(), yh.data_ptr(), head)
         torch.cuda.synchronize()
         xh = x[:2 * head].cpu().numpy()
-        model = oracle.fir_f32fma(taps, xh, decim, seg_mode=1, seg_len=32)
         l2, mx = oracle.err_metrics(yh.cpu().numpy(), oracle.fir_f64(taps, xh, decim))
-        parity = {"bit_exact_vs_f32_order_model": bool(np.array_equal(yh.cpu().numpy(), model)),
-                  "rel_l2_vs_f64_oracle": l2, "rel_max_vs_f64_oracle": mx, "window": "first 2^16 input samples"}
+        parity = {"rel_l2_vs_f64_oracle": l2, "rel_max_vs_f64_oracle": mx, "tolerance": 1e-6,
+                  "window": "first 2^16 input samples"}
+        if f2.get_backend() in (fir.BACKEND_HIP_DIRECT, fir.BACKEND_HIP_GENERIC):
+            model = oracle.fir_f32fma(taps, xh, decim, seg_mode=1, seg_len=32)
+            parity["bit_exact_vs_f32_order_model"] = bool(np.array_equal(yh.cpu().numpy(), model))
         f2.close()
         line = {
             "metric": "complex-IQ MSamples/s through %d-tap FIR" % taps_n,
@@ -231,14 +261,14 @@ def main():
             "config": {"workload": desc, "name": args.workload, "taps": taps_n, "decimation": decim,
                        "samples_per_channel": n, "channels_per_gpu": 1,
                        "parallelism": "channel-parallel x%d, no data-path collective" % world,
-                       "backend": {1: "hip_direct", 2: "hip_tapsplit", 3: "hip_generic", 4: "hip_fft"}[f.get_backend()],
+                       "backend": names[f.get_backend()],
                        "device": f.device_info()},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(dev_ms_max, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "HIP events on the launch stream around the timed steps / steps (includes the "
-                                 "~2 us history-update kernel); direct form is co-limited by the FP32 VALU: see valu"},
+                                 "history-update kernel and the queue memset)"},
             "valu": {"achieved": round(achieved_tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved_tf / VALU_PEAK_TFLOPS, 4)},
             "parity": parity,

@@ -99,7 +99,7 @@ def bpf_design(taps, f_low=0.15, f_high=0.25, window=WINDOW_BLACKMAN):
 class IfFir:
     """One if_fir_ctx_t.  Methods mirror the C entry points."""
 
-    def __init__(self, taps, decimation=1, max_samples=1 << 20, device=0):
+    def __init__(self, taps, decimation=1, max_samples=1 << 20, device=0, backend=None):
         taps = np.ascontiguousarray(taps, dtype=np.float32)
         self._ctx = ctypes.c_void_p()
         self.taps = taps
@@ -109,6 +109,8 @@ class IfFir:
         if not ok:
             self._ctx = ctypes.c_void_p()
             raise IfFirError(lib().if_fir_last_error(None).decode())
+        if backend is not None:
+            self.set_backend(backend)
 
     def _check(self, ok):
         if not ok:

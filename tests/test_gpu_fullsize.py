@@ -15,7 +15,7 @@ def test_full_size_windows_and_split_invariance(fir, oracle, gpu_ok, t, d, log2n
     torch.cuda.set_device(0)
     n = 1 << log2n
     taps = fir.bpf_design(t)
-    with fir.IfFir(taps, d, 0) as f:
+    with fir.IfFir(taps, d, 0, backend=fir.BACKEND_HIP_DIRECT) as f:
         x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
         m = f.out_count(n)
         y = torch.empty(2 * m, dtype=torch.float32, device="cuda")
@@ -58,3 +58,46 @@ def test_full_size_windows_and_split_invariance(fir, oracle, gpu_ok, t, d, log2n
         assert m1 + m2 == m
         assert torch.equal(y, y2)
         assert y2.double().sum().item() == ck1 and y2.double().abs().sum().item() == ab1 and ab1 > 0
+
+
+@pytest.mark.parametrize("t,d,log2n", [(255, 4, 28), (1023, 1, 28), (127, 1, 26)])
+def test_full_size_fft_backend(fir, oracle, gpu_ok, t, d, log2n):
+    """Overlap-save backend (AUTO) at BASELINE sizes: windows of the stream within SPEC tolerance of the float64 oracle,
+    and split invariance (one call vs two calls at an odd cut) within tolerance of each other."""
+    import torch
+    torch.cuda.set_device(0)
+    n = 1 << log2n
+    taps = fir.bpf_design(t)
+    with fir.IfFir(taps, d, 0) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+        m = f.out_count(n)
+        y = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        f.synth_device(x.data_ptr(), 0, n, 0)
+        assert f.process_device(x.data_ptr(), y.data_ptr(), n) == m
+        f.synchronize()
+        w = 8192
+        for start in [0, 3840 * 7 - 100, (n // 3) & ~3, n - w]:
+            lo = max(0, start - (t - 1))
+            xs = x[2 * lo:2 * (start + w)].cpu().numpy()
+            hist = np.zeros(2 * (t - 1), dtype=np.float32)
+            hist[2 * (t - 1 - (start - lo)):] = xs[:2 * (start - lo)]
+            ref = oracle.fir_f64(taps, xs[2 * (start - lo):], d, hist, start)
+            first_out = (start + d - 1) // d
+            got = y[2 * first_out:2 * first_out + ref.size].cpu().numpy()
+            l2, mx = oracle.err_metrics(got, ref)
+            assert l2 <= 1e-6 and mx <= 1e-6, (start, l2, mx)
+        f.reset()
+        cut = (n // 2) + 12345
+        y2 = torch.empty_like(y)
+        m1 = f.process_device(x.data_ptr(), y2.data_ptr(), cut)
+        tail = x[2 * cut:].clone()
+        ytail = torch.empty(2 * (m - m1), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        m2 = f.process_device(tail.data_ptr(), ytail.data_ptr(), n - cut)
+        f.synchronize()
+        assert m1 + m2 == m
+        y2[2 * m1:] = ytail
+        scale = y.abs().max().item()
+        assert (y - y2).abs().max().item() <= 1e-6 * scale   # block placement differs, values agree to tolerance

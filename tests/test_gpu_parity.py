@@ -33,6 +33,16 @@ def test_library_loaded_is_in_tree(fir, gpu_ok):
     assert os.path.dirname(fir.LIB_PATH).endswith("qo-100-tools_amd") and fir.lib() is not None
 
 
+def test_auto_backend_policy(fir, gpu_ok):
+    """AUTO = overlap-save where it applies (>= 32 taps, D in {1,4}, <= 1025 taps), else unrolled direct, else generic."""
+    expect = {(255, 4): fir.BACKEND_HIP_FFT, (255, 1): fir.BACKEND_HIP_FFT, (127, 1): fir.BACKEND_HIP_FFT,
+              (1023, 1): fir.BACKEND_HIP_FFT, (1023, 4): fir.BACKEND_HIP_FFT, (31, 1): fir.BACKEND_HIP_GENERIC,
+              (255, 2): fir.BACKEND_HIP_GENERIC, (2047, 1): fir.BACKEND_HIP_GENERIC}
+    for (t, d), b in expect.items():
+        with fir.IfFir(fir.bpf_design(t), d, 16) as f:
+            assert f.get_backend() == b, (t, d)
+
+
 def test_synth_device_bit_exact(fir, oracle, torch_cuda):
     torch = torch_cuda
     with fir.IfFir(fir.bpf_design(127), 1, 1 << 16) as f:
@@ -50,7 +60,7 @@ def test_direct_kernels_vs_oracle(fir, oracle, t, d, variant):
     rng = np.random.default_rng(100 * t + d)
     n = 70_001
     x = np.concatenate([oracle.synth_iq(n // 2), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
-    with fir.IfFir(taps, d, n) as f:
+    with fir.IfFir(taps, d, n, backend=fir.BACKEND_HIP_DIRECT) as f:
         assert f.get_backend() == fir.BACKEND_HIP_DIRECT
         f.set_tuning(variant)
         _check(oracle, f.process(x), taps, x, d)
@@ -62,7 +72,7 @@ def test_generic_kernel_vs_oracle(fir, oracle, t, d):
     taps = (fir.bpf_design(t) if t % 2 and t >= 3 else rng.standard_normal(t).astype(np.float32) / t)
     n = 20_011
     x = rng.standard_normal(2 * n).astype(np.float32)
-    with fir.IfFir(taps, d, n) as f:
+    with fir.IfFir(taps, d, n, backend=fir.BACKEND_HIP_GENERIC) as f:
         assert f.get_backend() == fir.BACKEND_HIP_GENERIC
         _check(oracle, f.process(x), taps, x, d)
 
@@ -70,7 +80,7 @@ def test_generic_kernel_vs_oracle(fir, oracle, t, d):
 def test_generic_backend_forced_equals_direct(fir, oracle):
     taps = fir.bpf_design(255)
     x = oracle.synth_iq(30_000, 2)
-    with fir.IfFir(taps, 4, 30_000) as f:
+    with fir.IfFir(taps, 4, 30_000, backend=fir.BACKEND_HIP_DIRECT) as f:
         a = f.process(x)
         f.reset()
         f.set_backend(fir.BACKEND_HIP_GENERIC)
@@ -80,6 +90,11 @@ def test_generic_backend_forced_equals_direct(fir, oracle):
             f.set_backend(fir.BACKEND_HIP_TAPSPLIT)   # not built this round: must say so, context stays usable
         f.reset()
         assert np.array_equal(f.process(x), b)
+        f.set_backend(fir.BACKEND_AUTO)          # AUTO = overlap-save here: same answer within SPEC tolerance
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        f.reset()
+        l2, mx = oracle.err_metrics(f.process(x), oracle.fir_f64(taps, x, 4))
+        assert l2 <= TOL and mx <= TOL
 
 
 @pytest.mark.parametrize("t", [127, 255, 1023])
@@ -100,11 +115,16 @@ def test_config0_real_samples_through_complex_path(fir, oracle):
     xr = oracle.synth_iq(1 << 20)[0::2].copy()
     x = np.zeros(2 * xr.size, dtype=np.float32)
     x[0::2] = xr
-    with fir.IfFir(taps, 1, xr.size) as f:
-        y = f.process(x)
     ref = oracle.fir_real_f64(taps, xr)
+    with fir.IfFir(taps, 1, xr.size, backend=fir.BACKEND_HIP_DIRECT) as f:
+        y = f.process(x)
+        l2, mx = oracle.err_metrics(y[0::2], ref)
+        assert l2 <= TOL and mx <= TOL and not np.any(y[1::2])      # direct form: Q stays exactly zero
+        f.set_backend(fir.BACKEND_AUTO)                              # overlap-save: Q is rounding noise
+        f.reset()
+        y = f.process(x)
     l2, mx = oracle.err_metrics(y[0::2], ref)
-    assert l2 <= TOL and mx <= TOL and not np.any(y[1::2])
+    assert l2 <= TOL and mx <= TOL and np.max(np.abs(y[1::2])) <= TOL * np.max(np.abs(ref))
     # and the committed 4096-sample real fixture
     x4 = np.zeros(2 * 4096, dtype=np.float32)
     x4[0::2] = g["xr"]
@@ -122,7 +142,8 @@ def test_streaming_ragged_pieces(fir, oracle, t, d):
     x = oracle.synth_iq(n, 1)
     one = oracle.fir_f32fma(taps, x, d, **SEG)
     cuts = [0, 0, 1, 3, 10, 11, 200, 253, 254, 255, 511, 8192 + 511, 8192 + 512, 2 * 8192 + 513, 30_001, n]
-    with fir.IfFir(taps, d, n) as f:
+    bit_exact_backend = fir.BACKEND_HIP_DIRECT if (t, d) != (31, 3) else fir.BACKEND_HIP_GENERIC
+    with fir.IfFir(taps, d, n, backend=bit_exact_backend) as f:
         parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
         assert np.array_equal(np.concatenate(parts), one)
         f.reset()
@@ -134,7 +155,7 @@ def test_sizes_around_tile_edges(fir, oracle, n):
     for t, d in [(255, 4), (255, 1)]:
         taps = fir.bpf_design(t)
         x = oracle.synth_iq(n, 3)
-        with fir.IfFir(taps, d, n) as f:
+        with fir.IfFir(taps, d, n, backend=fir.BACKEND_HIP_DIRECT) as f:
             _check(oracle, f.process(x), taps, x, d)
 
 
@@ -142,7 +163,7 @@ def test_impulse_and_zero_input(fir, oracle):
     taps = fir.bpf_design(255)
     x = np.zeros(2 * 1000, dtype=np.float32)
     x[0], x[1] = 1.0, -2.0
-    with fir.IfFir(taps, 1, 1000) as f:
+    with fir.IfFir(taps, 1, 1000, backend=fir.BACKEND_HIP_DIRECT) as f:
         y = f.process(x)
         assert np.array_equal(y[0:510:2], taps) and np.array_equal(y[1:510:2], -2 * taps) and not np.any(y[510:])
         assert f.process(np.zeros(0, dtype=np.float32)).size == 0
@@ -161,7 +182,7 @@ def test_device_api_canaries_and_errors(fir, oracle, torch_cuda):
     xin = torch.from_numpy(x).cuda()
     out = torch.full((2 * m + 2 * guard,), 12345.0, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    with fir.IfFir(taps, d, n) as f:
+    with fir.IfFir(taps, d, n, backend=fir.BACKEND_HIP_DIRECT) as f:
         with pytest.raises(fir.IfFirError, match="aligned"):
             f.process_device(xin.data_ptr() + 4, out.data_ptr(), n - 1)
         got = f.process_device(xin.data_ptr(), out.data_ptr() + 4 * guard, n)
@@ -187,7 +208,7 @@ def test_caller_stream(fir, oracle, torch_cuda):
     n = 20_000
     x = oracle.synth_iq(n)
     s = torch.cuda.Stream()
-    with fir.IfFir(taps, 1, n) as f, torch.cuda.stream(s):
+    with fir.IfFir(taps, 1, n, backend=fir.BACKEND_HIP_DIRECT) as f, torch.cuda.stream(s):
         f.set_stream(s.cuda_stream)
         xin = torch.from_numpy(x).cuda(non_blocking=False)
         out = torch.empty(2 * n, dtype=torch.float32, device="cuda")
@@ -205,7 +226,7 @@ def test_fft_backend_vs_oracle(fir, oracle, t):
     n = 50_021
     x = np.concatenate([oracle.synth_iq(n // 2, 5), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
     ref = oracle.fir_f64(taps, x, 1)
-    with fir.IfFir(taps, 1, n) as f:
+    with fir.IfFir(taps, 1, n, backend=fir.BACKEND_HIP_DIRECT if t in (127, 255) else fir.BACKEND_HIP_GENERIC) as f:
         direct = f.process(x)
         f.reset()
         f.set_backend(fir.BACKEND_HIP_FFT)
