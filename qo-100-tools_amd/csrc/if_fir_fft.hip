@@ -222,9 +222,15 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
     void *q = (void *)(((uint64_t)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
 }
+#ifndef IF_FIR_FFT_LOAD_AUX
+#define IF_FIR_FFT_LOAD_AUX 0
+#endif
+#ifndef IF_FIR_FFT_STORE_AUX
+#define IF_FIR_FFT_STORE_AUX 0
+#endif
 __device__ __forceinline__ cf buf_load(srd_t rsrc, unsigned voff, unsigned soff)
 {
-    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, IF_FIR_FFT_LOAD_AUX);
     return (cf){__uint_as_float(v[0]), __uint_as_float(v[1])};
 }
 __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned soff, cf d)
@@ -232,7 +238,7 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
     u32x2_t v;
     v[0] = __float_as_uint(d.x);
     v[1] = __float_as_uint(d.y);
-    __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, IF_FIR_FFT_STORE_AUX);
 }
 
 // one returning atomic add issued by lane 0 only, WITHOUT the wait hipcc would put right behind it (that wait is a
@@ -307,8 +313,8 @@ template <int OVL_ROWS, bool DEC4>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
-                                                        int32_t waves_total, int32_t RUN, unsigned int *queue, unsigned long long *dbg,
-                                                        int32_t diag)
+                                                        int32_t waves_total, int32_t RA, int32_t nA, int32_t RB, int32_t nB,
+                                                        unsigned int *queue, unsigned long long *dbg, int32_t diag)
 {
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
@@ -350,11 +356,31 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #else
 #define FFT_STAMP(slot) (void)0
 #endif
-    // Work distribution: run q = blocks [q*RUN, (q+1)*RUN).  Wave w starts with run w; further runs come from one
-    // atomic counter, reserved a whole run ahead.  (One ticket per BLOCK saturates the counter: a single address takes
+    // Work distribution: wave w starts with ticket w; further tickets come from one atomic counter, reserved a whole
+    // run ahead.  (One ticket per BLOCK saturates the counter: a single address takes
     // ~88 atomics/us, 70k blocks would cost 0.8 ms by themselves.)
-    int64_t blk = ((int64_t)blockIdx.x * FFT_WAVES + wid) * RUN;
-    int64_t blk_end = blk + RUN < nblocks ? blk + RUN : nblocks;
+    // guided schedule: tickets [0, nA) are runs of RA blocks, the next nB tickets runs of RB blocks, the rest single
+    // blocks, so that the tail of the launch is handed out in small pieces and all waves finish together
+    auto run_range = [&](int64_t q, int64_t &b0, int64_t &b1) {
+        if (q < nA)
+        {
+            b0 = q * RA;
+            b1 = b0 + RA;
+        }
+        else if (q < (int64_t)nA + nB)
+        {
+            b0 = (int64_t)nA * RA + (q - nA) * RB;
+            b1 = b0 + RB;
+        }
+        else
+        {
+            b0 = (int64_t)nA * RA + (int64_t)nB * RB + (q - nA - nB);
+            b1 = b0 + 1;
+        }
+        b1 = b1 < nblocks ? b1 : nblocks;
+    };
+    int64_t blk, blk_end;
+    run_range((int64_t)blockIdx.x * FFT_WAVES + wid, blk, blk_end);
     unsigned int ticket = 0;
     bool ticket_pending = false;
     cf r[64];
@@ -420,7 +446,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     r[4 * j + rho] = cmul_v<false>(t[j], w);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         FFT_STAMP(2);
         exchange1_fwd(r);
@@ -443,7 +468,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     r[phys(i, j)] = cmul_v<false>(t[j], w);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         FFT_STAMP(3);
         exchange2(r, xb, lane);
@@ -451,8 +475,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         int64_t blk_next = blk + 1;
         if (blk_next >= blk_end)
         {
-            blk_next = ((int64_t)waves_total + (int64_t)queue_ticket_wait(ticket)) * RUN;
-            blk_end = blk_next + RUN < nblocks ? blk_next + RUN : nblocks;
+            run_range((int64_t)waves_total + (int64_t)queue_ticket_wait(ticket), blk_next, blk_end);
             ticket_pending = false;
         }
         const int64_t s0n = blk_next * L - OVL + n0;
@@ -488,12 +511,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int j = 0; j < 16; j++)
                         r[phys(i, j)] = buf_load(nsrd, voff, phys(i, j) * 512);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                }
             FFT_STAMP(5);
             cf c[16];
             inverse_dec4(z, c, twd, twe, xb, lane);
-            __builtin_amdgcn_sched_barrier(0);
             if (next_fast)
             {
 #pragma unroll
@@ -526,8 +547,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     r[phys(i, j)] = t[j];
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                }
             exchange2(r, xb, lane);
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -545,8 +565,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     r[phys(i, j)] = t[j];
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                }
             exchange1_inv(r);
             // ---- last inverse pass, group by group: finish 16 rows, store them, and refill the same registers with
             //      the next block's rows (the loads fly while the remaining groups and the next forward pass compute)
@@ -576,8 +595,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int j = 0; j < 16; j++)
                         r[4 * j + rho] = buf_load(nsrd, voff, (4 * j + rho) * 512);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                }
         }
         FFT_STAMP(7);
         dbg_it++;
@@ -611,21 +629,30 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     const int64_t nblocks = (a.M + LOUT - 1) / LOUT;
     if (nblocks <= 0)
         return hipSuccess;
-    // blocks per queue ticket: long enough to keep the counter far from saturation (~88 tickets/us), short enough that
-    // the last runs do not leave waves idle (at least ~6 runs per wave)
-    int64_t run = nblocks / ((int64_t)cus[dev] * FFT_WAVES * 6);
-    run = run < 1 ? 1 : (run > 8 ? 8 : run);
-    const int64_t nruns = (nblocks + run - 1) / run;
+    // guided schedule (see the kernel): ~80 % of the blocks in runs of RA, ~15 % in runs of RB, the rest singly.  Runs
+    // keep the counter far from saturation (~88 tickets/us); small pieces at the end keep the tail short.
+    const int64_t waves_max = (int64_t)cus[dev] * FFT_WAVES;
+    int64_t RA = nblocks / (waves_max * 4);
+    RA = RA < 1 ? 1 : (RA > 8 ? 8 : RA);
+    int64_t RB = RA >= 4 ? 2 : 1;
+    int64_t nA = (nblocks * 8 / 10) / RA;
+    if (nA < waves_max && nA * RA < nblocks)
+        nA = (nblocks / RA < waves_max) ? nblocks / RA : waves_max; // every wave starts with a full run when possible
+    int64_t nB = RB > 1 ? (nblocks * 15 / 100) / RB : 0;
+    if (nA * RA + nB * RB > nblocks)
+        nB = (nblocks - nA * RA) / RB;
+    const int64_t tickets = nA + nB + (nblocks - nA * RA - nB * RB);
     int64_t wgs = cus[dev];
-    if (wgs * FFT_WAVES > nruns)
-        wgs = (nruns + FFT_WAVES - 1) / FFT_WAVES;
+    if (wgs * FFT_WAVES > tickets)
+        wgs = (tickets + FFT_WAVES - 1) / FFT_WAVES;
     hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), FFT_LDS_BYTES, a.stream,
                        reinterpret_cast<const f2v *>(a.in), reinterpret_cast<f2v *>(a.out),
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist), a.T, a.N,
-                       a.n0, a.M, nblocks, (int32_t)(wgs * FFT_WAVES), (int32_t)run, (unsigned int *)a.queue,
+                       a.n0, a.M, nblocks, (int32_t)(wgs * FFT_WAVES), (int32_t)RA, (int32_t)nA, (int32_t)RB, (int32_t)nB,
+                       (unsigned int *)a.queue,
                        (unsigned long long *)a.dbg, (int32_t)a.diag);
     return hipGetLastError();
 }
