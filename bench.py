@@ -35,6 +35,7 @@ WORKLOADS = {
     "fir127_2p26": (127, 1, 26, "127-tap complex-IQ FIR, one channel per GPU, 2^26 IQ samples (BASELINE configs[1])"),
     "fir255_2p28": (255, 1, 28, "255-tap complex-IQ FIR, no decimation, one channel per GPU, 2^28 IQ samples"),
     "fir255_dec4_2p24": (255, 4, 24, "255-tap + decimate-by-4, 2^24 IQ samples (quick check size)"),
+    "fir2047_dec8_2p26": (2047, 8, 26, "2047-tap FIR, decimate-by-8, 2^26 IQ samples (tap-split kernel territory)"),
     "fir1023_2p28": (1023, 1, 28, "1023-tap complex-IQ FIR, one channel per GPU, 2^28 IQ samples (BASELINE configs[4])"),
 }
 

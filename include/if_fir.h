@@ -44,9 +44,9 @@ enum
 {
     IF_FIR_BACKEND_AUTO = 0,
     IF_FIR_BACKEND_HIP_DIRECT = 1,  /* register-blocked sample-stationary direct form, taps in SGPRs            */
-    IF_FIR_BACKEND_HIP_TAPSPLIT = 2,/* taps staged in LDS, split over 4 lanes, partial sums reduced with DPP     */
-    IF_FIR_BACKEND_HIP_GENERIC = 3, /* any T ≤ 4096, any D ≤ 64 (rolled loops)                                    */
-    IF_FIR_BACKEND_HIP_FFT = 4      /* overlap-save, 4096-point LDS-resident FFT (T ≤ 1025, D = 1)               */
+    IF_FIR_BACKEND_HIP_TAPSPLIT = 2,/* any T, D: taps staged in LDS, split over 4 lanes, partial sums DPP-reduced */
+    IF_FIR_BACKEND_HIP_GENERIC = 3, /* any T, D: one output per thread (simple cross-check kernel)                */
+    IF_FIR_BACKEND_HIP_FFT = 4      /* overlap-save, wave-private 4096-point FFT (T ≤ 1025, D = 1 or 4); AUTO's pick */
 };
 
 /* window ids for if_bpf_design */

@@ -193,10 +193,52 @@ ORACLE_API uint64_t oracle_fir_r32_f64(const float *pfTaps, uint32_t T, const fl
 /*   ulSegMode 0: one chain over all taps.                                                      */
 /*   ulSegMode 1: contiguous segments of ulSegLen taps, segment s = taps [s·L, (s+1)·L).         */
 /*   ulSegMode 2: residue classes, segment s = taps with k mod ulSegLen == s.                    */
+/*   ulSegMode 3: tap-split kernel: lane q of a quad owns the taps k = 4j + q (j descending);    */
+/*                inside a lane, segments of ulSegLen consecutive j (aligned to multiples of    */
+/*                ulSegLen) are added as they complete; the four lane sums are combined        */
+/*                pairwise as (q0 + q1) + (q2 + q3)  (two DPP butterfly steps).                  */
 /*   Inside a segment taps are visited in DESCENDING k with acc = fmaf(x, h, acc), acc0 = +0;   */
 /*   segments are added in the order they complete, i.e. DESCENDING s:                          */
 /*   tot = seg[S-1]; tot += seg[S-2]; … ; tot += seg[0]   (plain float adds).                    */
 /* ------------------------------------------------------------------------------------------- */
+static void oracle_chain_residue(const float *pfTaps, uint32_t T, const float *pfHist, const float *pfIn, int64_t n,
+                                 uint32_t q, uint32_t L, float *pI, float *pQ)
+{
+    /* taps k = 4j + q < T, j descending, segments of L consecutive j aligned to multiples of L */
+    float ti = 0.0f, tq = 0.0f, ai = 0.0f, aq = 0.0f;
+    int have_tot = 0;
+    const int64_t J = ((int64_t)T + 3) / 4;
+    for (int64_t j = J - 1; j >= 0; j--)
+    {
+        const int64_t k = 4 * j + q;
+        if (k < (int64_t)T)
+        {
+            float xi, xq;
+            oracle_fetch(pfHist, T, pfIn, n - k, &xi, &xq);
+            ai = fmaf(xi, pfTaps[k], ai);
+            aq = fmaf(xq, pfTaps[k], aq);
+        }
+        if (j % (int64_t)L == 0)
+        {
+            if (have_tot)
+            {
+                ti += ai;
+                tq += aq;
+            }
+            else
+            {
+                ti = ai;
+                tq = aq;
+                have_tot = 1;
+            }
+            ai = 0.0f;
+            aq = 0.0f;
+        }
+    }
+    *pI = ti;
+    *pQ = tq;
+}
+
 ORACLE_API uint64_t oracle_fir_c64_f32fma(const float *pfTaps, uint32_t T, uint32_t D, const float *pfHist,
                                          uint64_t ullConsumed, const float *pfIn, uint64_t N, float *pfOut,
                                          uint32_t ulSegMode, uint32_t ulSegLen)
@@ -213,6 +255,15 @@ ORACLE_API uint64_t oracle_fir_c64_f32fma(const float *pfTaps, uint32_t T, uint3
     {
         const int64_t n = n0 + m * (int64_t)D;
         float ti = 0.0f, tq = 0.0f;
+        if (ulSegMode == 3)
+        {
+            float qi[4], qq[4];
+            for (uint32_t q = 0; q < 4; q++)
+                oracle_chain_residue(pfTaps, T, pfHist, pfIn, n, q, ulSegLen, &qi[q], &qq[q]);
+            pfOut[2 * m] = (qi[0] + qi[1]) + (qi[2] + qi[3]);
+            pfOut[2 * m + 1] = (qq[0] + qq[1]) + (qq[2] + qq[3]);
+            continue;
+        }
         for (int64_t ss = (int64_t)nseg - 1; ss >= 0; ss--)
         {
             const uint32_t s = (uint32_t)ss;

@@ -450,6 +450,113 @@ __global__ __launch_bounds__(256, WPS) void fir_direct_wave_kernel(const f2 *__r
 }
 
 // --------------------------------------------------------------------------------------------------------------
+// tap-split kernel (the north_star's wording made literal): any T <= 4096, any D <= 64.
+//   * the taps are staged in LDS, de-interleaved by k mod 4, so that lane q of every quad owns the taps 4j+q and
+//     reads four of them per ds_read_b128;
+//   * the input tile (+ T-1 halo) is staged in LDS with coalesced loads; the 4 lanes of a quad read 4 neighbouring
+//     samples per step (bank-conflict free), each lane feeding R_TS = 4 accumulators (outputs 64 apart) so a tap
+//     fetched from LDS is used four times;
+//   * the four partial sums of a quad are reduced with two DPP butterfly steps (quad_perm xor 1, xor 2):
+//     (s0 + s1) + (s2 + s3); lane 0 of the quad stores.
+// Summation order = oracle mode 3 (SPEC §3): inside a lane descending j, segments of SEG steps.
+// --------------------------------------------------------------------------------------------------------------
+constexpr int TS_R = 4;         // outputs per lane
+constexpr int TS_TILE = 256;    // outputs per workgroup (64 quads x 4)
+constexpr int TS_MAX_LDS = 150 * 1024;
+
+__device__ __forceinline__ float dpp_xor1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
+}
+
+template <int SEG>
+__global__ __launch_bounds__(256) void fir_tapsplit_kernel(const f2 *__restrict__ in, f2 *__restrict__ out,
+                                                          const float *__restrict__ taps,
+                                                          const f2 *__restrict__ hist, int T, int D, int64_t N,
+                                                          int32_t n0, int64_t M, int32_t tile_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int J = (T + 3) / 4;                 // steps per lane
+    const int J4 = (J + 3) & ~3;               // padded to whole b128 reads
+    float *tl = reinterpret_cast<float *>(smem);                 // tl[q*J4 + j] = h[4j+q] (0 beyond T)
+    f2 *xs = reinterpret_cast<f2 *>(smem + 16 * J4);             // staged samples
+    for (int i = tid; i < 4 * J4; i += 256)
+    {
+        const int q = i / J4, j = i - q * J4, k = 4 * j + q;
+        tl[i] = (j < J && k < T) ? taps[k] : 0.0f;
+    }
+    const int64_t m_t = (int64_t)blockIdx.x * tile_out;          // first output of the tile
+    const int64_t s_lo = (int64_t)n0 + m_t * D - (T - 1);        // stream index of xs[0]
+    const int count = (tile_out - 1) * D + T;
+    for (int i = tid; i < count; i += 256)
+        xs[i] = fetch_sample(in, hist, T, s_lo + i, N);
+    __syncthreads();
+
+    const int quad = tid >> 2, q = tid & 3;
+    const int per_quad = tile_out / 64;        // 1..4 outputs per lane, 64 apart
+    f2 acc[TS_R], tot[TS_R];
+    bool have_tot = false;
+    int pos[TS_R];
+#pragma unroll
+    for (int r = 0; r < TS_R; r++)
+    {
+        acc[r] = (f2){0.f, 0.f};
+        tot[r] = (f2){0.f, 0.f};
+        const int o = quad + 64 * (r < per_quad ? r : 0);        // unused slots recompute slot 0 (results dropped)
+        pos[r] = o * D + (T - 1) - q;                            // xs index of this lane's sample for j = 0
+    }
+    const float *tq = tl + q * J4;
+    for (int jb = J4 - 4; jb >= 0; jb -= 4)
+    {
+        const f4 h4 = *reinterpret_cast<const f4 *>(tq + jb);
+        const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+        for (int u = 3; u >= 0; u--)
+        {
+            const int j = jb + u;
+            if (j < J)
+            {
+                const float h = hh[u];
+#pragma unroll
+                for (int r = 0; r < TS_R; r++)
+                {
+                    const int xi = pos[r] - 4 * j;
+                    const f2 x = (xi >= 0) ? xs[xi] : (f2){0.f, 0.f}; // 4j+q beyond T-1 only meets zero taps
+                    acc[r] = __builtin_elementwise_fma(x, (f2){h, h}, acc[r]);
+                }
+                if (j % SEG == 0)
+                {
+#pragma unroll
+                    for (int r = 0; r < TS_R; r++)
+                    {
+                        tot[r] = have_tot ? tot[r] + acc[r] : acc[r];
+                        acc[r] = (f2){0.f, 0.f};
+                    }
+                    have_tot = true;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TS_R; r++)
+    {
+        f2 v = tot[r];
+        v.x += dpp_xor1(v.x);
+        v.y += dpp_xor1(v.y);
+        v.x += dpp_xor2(v.x);
+        v.y += dpp_xor2(v.y);
+        const int64_t m = m_t + quad + 64 * r;
+        if (q == 0 && r < per_quad && m < M)
+            out[m] = v;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
 // generic kernel: any T ≤ 4096, any D ≤ 64.  One output per thread, taps read through the scalar cache
 // (uniform index), samples straight from global/L2 (neighbouring lanes share lines).  Same summation order
 // as the fast kernels (descending k, segments of SEG).  Correctness fallback, not a performance path.
@@ -661,6 +768,37 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             }
         }
         return hipErrorInvalidConfiguration;
+    }
+    if (a.backend == BACKEND_TAPSPLIT)
+    {
+        if (a.M <= 0)
+            return hipSuccess;
+        // tile: as many outputs (64..256, multiple of 64) as keep taps + samples inside the LDS budget
+        const int J4 = (((a.T + 3) / 4) + 3) & ~3;
+        int tile = TS_TILE;
+        while (tile > 64 && 16 * J4 + 8 * ((int64_t)(tile - 1) * a.D + a.T) > TS_MAX_LDS)
+            tile -= 64;
+        const int64_t lds = 16 * J4 + 8 * ((int64_t)(tile - 1) * a.D + a.T);
+        if (lds > TS_MAX_LDS)
+            return hipErrorInvalidConfiguration;
+        auto kern = fir_tapsplit_kernel<32>;
+        static bool attr_done[16] = {false};
+        const int dev = a.device & 15;
+        if (!attr_done[dev])
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, TS_MAX_LDS);
+            if (e != hipSuccess)
+                return e;
+            attr_done[dev] = true;
+        }
+        const int64_t blocks = (a.M + tile - 1) / tile;
+        if (blocks > 0x7fffffffLL)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), (size_t)lds, a.stream,
+                           reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,
+                           reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M, (int32_t)tile);
+        return hipGetLastError();
     }
     if (a.backend == BACKEND_GENERIC)
     {

@@ -34,10 +34,10 @@ def test_library_loaded_is_in_tree(fir, gpu_ok):
 
 
 def test_auto_backend_policy(fir, gpu_ok):
-    """AUTO = overlap-save where it applies (>= 32 taps, D in {1,4}, <= 1025 taps), else unrolled direct, else generic."""
+    """AUTO = overlap-save where it applies (>= 32 taps, D in {1,4}, <= 1025 taps), else unrolled direct, else tap-split."""
     expect = {(255, 4): fir.BACKEND_HIP_FFT, (255, 1): fir.BACKEND_HIP_FFT, (127, 1): fir.BACKEND_HIP_FFT,
-              (1023, 1): fir.BACKEND_HIP_FFT, (1023, 4): fir.BACKEND_HIP_FFT, (31, 1): fir.BACKEND_HIP_GENERIC,
-              (255, 2): fir.BACKEND_HIP_GENERIC, (2047, 1): fir.BACKEND_HIP_GENERIC}
+              (1023, 1): fir.BACKEND_HIP_FFT, (1023, 4): fir.BACKEND_HIP_FFT, (31, 1): fir.BACKEND_HIP_TAPSPLIT,
+              (255, 2): fir.BACKEND_HIP_TAPSPLIT, (2047, 1): fir.BACKEND_HIP_TAPSPLIT}
     for (t, d), b in expect.items():
         with fir.IfFir(fir.bpf_design(t), d, 16) as f:
             assert f.get_backend() == b, (t, d)
@@ -87,7 +87,7 @@ def test_generic_backend_forced_equals_direct(fir, oracle):
         b = f.process(x)
         assert np.array_equal(a, b)
         with pytest.raises(fir.IfFirError):
-            f.set_backend(fir.BACKEND_HIP_TAPSPLIT)   # not built this round: must say so, context stays usable
+            f.set_backend(9)                          # unknown backend: refused with a message, context stays usable
         f.reset()
         assert np.array_equal(f.process(x), b)
         f.set_backend(fir.BACKEND_AUTO)          # AUTO = overlap-save here: same answer within SPEC tolerance
@@ -298,3 +298,30 @@ def test_fft_backend_decimate4_block_edges(fir, oracle, n):
     ref = oracle.fir_f64(taps, x, 4)
     assert y.shape == ref.shape
     assert np.max(np.abs(y - ref)) <= 1e-6 * max(np.max(np.abs(ref)), 0.5), (n, np.max(np.abs(y - ref)))
+
+
+TS = dict(seg_mode=3, seg_len=32)
+
+
+@pytest.mark.parametrize("t,d", [(1, 1), (2, 2), (3, 1), (5, 3), (31, 3), (64, 1), (255, 4), (255, 5), (1023, 1),
+                                 (1023, 4), (2047, 8), (4096, 64), (4095, 1), (127, 16)])
+def test_tapsplit_kernel_vs_oracle(fir, oracle, t, d):
+    """Tap-split kernel (taps in LDS, 4 lanes per output, DPP reduction): bit-exact against the oracle's order model
+    (mode 3) and within SPEC tolerance of the float64 oracle, for any (T, D), one-shot and streamed."""
+    rng = np.random.default_rng(7 * t + d)
+    taps = (fir.bpf_design(t) if t % 2 and t >= 3 else rng.standard_normal(t).astype(np.float32) / max(t, 1))
+    n = 30_011
+    x = np.concatenate([oracle.synth_iq(n // 2, 11), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
+    model = oracle.fir_f32fma(taps, x, d, **TS)
+    ref = oracle.fir_f64(taps, x, d)
+    with fir.IfFir(taps, d, n, backend=fir.BACKEND_HIP_TAPSPLIT) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_TAPSPLIT
+        y = f.process(x)
+        assert np.array_equal(y, model), np.max(np.abs(y - model))
+        if np.any(ref):
+            l2, mx = oracle.err_metrics(y, ref)
+            assert l2 <= TOL and mx <= TOL, (l2, mx)
+        f.reset()
+        cuts = [0, 1, 2, 77, 255, 256, 4097, 9000, 20_001, n]
+        parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts), model)

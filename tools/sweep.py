@@ -25,11 +25,15 @@ def main():
         f.synth_device(x.data_ptr(), 0, n, 0)
         f.synchronize()
         for v in variants:
-            if v >= 100:
+            if v == 200:
+                f.set_backend(fir.BACKEND_HIP_TAPSPLIT)
+            elif v == 300:
+                f.set_backend(fir.BACKEND_HIP_GENERIC)
+            elif v >= 100:
                 f.set_backend(fir.BACKEND_HIP_FFT)
                 f.set_tuning(v if v >= 1000 else 0)   # 1001/1002/1003: FFT diagnostics (skip loads / stores / both)
             else:
-                f.set_backend(fir.BACKEND_AUTO)
+                f.set_backend(fir.BACKEND_HIP_DIRECT)
                 f.set_tuning(v)
             f.reset()
             y.zero_()
