@@ -231,7 +231,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                key = args.workload + (":fir_fft" if f.get_backend() == fir.BACKEND_HIP_FFT else ":fir_direct")
+                traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         # parity spot check (oracle as checker only): first 4096 outputs of this rank's last step vs the order model.

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """collect_profiles.py — condenses rocprofv3 output under gpurun_out/ into the tracked summaries under profiles/.
 
-usage: python tools/collect_profiles.py <round tag> <workload> <kernel-trace dir> <pmc fetch dir> <pmc write dir>
+usage: python tools/collect_profiles.py <round tag> <workload> <kernel-trace dir> <pmc fetch dir> <pmc write dir> [kernel substring]
 Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --stats), profiles/<tag>_kernel_trace_summary.json and
 updates profiles/traffic.json (HBM bytes per launch from the TCC counters, gfx950 correction applied:
 FETCH_SIZE counts 128-byte read requests as 64 bytes for 16-byte-per-lane streaming loads — calibrated in the same
@@ -19,11 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag, workload, ktrace, pfetch, pwrite = sys.argv[1:6]
+    ksub = sys.argv[6] if len(sys.argv) > 6 else "fir_fft"
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     stats = glob.glob(os.path.join(ktrace, "**", "*kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats, os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
     trace = glob.glob(os.path.join(ktrace, "**", "*kernel_trace.csv"), recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(trace)) if "fir_direct" in r["Kernel_Name"] or "fir_fft" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(trace)) if ksub in r["Kernel_Name"]]
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
     full = [d for d in durs if d > 0.5 * max(durs)]          # drop the small parity-check launch
     summ = {"kernel": rows[0]["Kernel_Name"].split("(")[0], "launches": len(full),
@@ -36,7 +37,7 @@ def main():
     def counter(d, name):
         f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                if r["Counter_Name"] == name and ("fir_direct" in r["Kernel_Name"] or "fir_fft" in r["Kernel_Name"])]
+                if r["Counter_Name"] == name and ksub in r["Kernel_Name"]]
         vals = [v for v in vals if v > 0.5 * max(vals)]
         return sum(vals) / len(vals), len(vals)
 
@@ -44,7 +45,8 @@ def main():
     write_kb, nw = counter(pwrite, "WRITE_SIZE")
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    traffic[workload] = {
+    traffic[workload + ":" + ksub] = {
+        "kernel": rows[0]["Kernel_Name"].split("(")[0],
         "round": tag, "FETCH_SIZE_KiB_per_launch": fetch_kb, "WRITE_SIZE_KiB_per_launch": write_kb,
         "launches_averaged": [nf, nw],
         "read_bytes_per_launch": 2.0 * fetch_kb * 1024.0, "write_bytes_per_launch": write_kb * 1024.0,
@@ -53,7 +55,7 @@ def main():
                       "reported FETCH_SIZE = 1.000 GiB in the same session); WRITE_SIZE exact"}
     json.dump(traffic, open(tpath, "w"), indent=1)
     print(json.dumps(summ)[:400])
-    print(json.dumps(traffic[workload]))
+    print(json.dumps(traffic[workload + ":" + ksub]))
 
 
 if __name__ == "__main__":
