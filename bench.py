@@ -88,6 +88,10 @@ def cpu_baseline(taps_arr, decim, budget_s=12.0):
 
 
 def main():
+    # Everything except the final JSON line goes to stderr: RCCL prints a version banner on stdout at communicator
+    # creation, which would break the one-line contract.
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -112,8 +116,13 @@ def main():
         raise SystemExit("bench.py needs a HIP device: libif_fir has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # IF_FIR_BENCH_DIST=1 runs the collective code path (RCCL init, barriers, MAX-reduce) even with one rank, so it can
+    # be rehearsed on a one-GPU box
+    use_dist = world > 1 or os.environ.get("IF_FIR_BENCH_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = graft.load_pkg()
@@ -143,7 +152,7 @@ def main():
     for _ in range(args.warmup):
         step_stream()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -154,13 +163,13 @@ def main():
         step_stream()
     ev1.record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
     t = torch.tensor([wall, dev_ms_per_step], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, dev_ms_max = float(t[0].item()), float(t[1].item())
 
@@ -189,7 +198,7 @@ def main():
             "note": "hand-written v_pk_fma_f32 direct form (bit-exact vs the oracle's float32 order model); power-limited"}
         f.set_backend(fir.BACKEND_AUTO)
         f.reset()
-    if args.scatter and world > 1:
+    if args.scatter and use_dist:
         cs = pkg.channel_shard
         root_inputs = None
         if rank == 0:
@@ -279,9 +288,9 @@ def main():
             line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(taps, decim)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     f.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -255,9 +255,7 @@ struct AsmWalk;
         static __device__ __forceinline__ void run(unsigned a, const float *t, f2 (&tot)[R_]) { FN_(a, t, tot); } \
     };
 IF_FIR_ASM_WALK(255, 4, 8, 32, 0, walk_asm_T255_D4_R8_S32)
-IF_FIR_ASM_WALK(255, 4, 8, 32, 1, walk_asm_T255_D4_R8_S32_q6)
 IF_FIR_ASM_WALK(255, 4, 8, 32, 2, walk_asm_T255_D4_R8_S32_b128)
-IF_FIR_ASM_WALK(255, 4, 8, 32, 3, walk_asm_T255_D4_R8_S32_b128q3)
 IF_FIR_ASM_WALK(255, 1, 8, 32, 0, walk_asm_T255_D1_R8_S32)
 IF_FIR_ASM_WALK(255, 1, 16, 32, 0, walk_asm_T255_D1_R16_S32)
 IF_FIR_ASM_WALK(127, 1, 8, 32, 0, walk_asm_T127_D1_R8_S32)
@@ -286,8 +284,8 @@ __global__ __launch_bounds__(256, WPS) void fir_direct_wave_kernel(const f2 *__r
                                                                   const float *__restrict__ taps,
                                                                   const f2 *__restrict__ hist, int64_t N, int32_t n0,
                                                                   int64_t M, int64_t tiles_total, int32_t run_len,
-                                                                  int32_t waves_total, unsigned int *queue,
-                                                                  unsigned long long *dbg)
+                                                                  int32_t n_long, int32_t waves_total,
+                                                                  unsigned int *queue, unsigned long long *dbg)
 {
     using G = WGeo<T, D, R>;
     constexpr int HU = G::HALO / 2;                        // 16-byte units in the halo
@@ -303,7 +301,8 @@ __global__ __launch_bounds__(256, WPS) void fir_direct_wave_kernel(const f2 *__r
     const unsigned lds_lane_addr = (unsigned)(uintptr_t)(lds_char_t *)smem + (unsigned)(wid * G::WAVE_LDS + lane * G::CH);
     const int64_t gw = (int64_t)blockIdx.x * 4 + wid;
     const bool aligned = ((n0 & 1) == 0);
-    const int64_t runs_total = (tiles_total + run_len - 1) / run_len;
+    // guided schedule: tickets [0, n_long) are runs of run_len tiles, later tickets single tiles (short tail)
+    const int64_t runs_total = (int64_t)n_long + (tiles_total - (int64_t)n_long * run_len);
 
     // Work distribution: run r = tiles [r*run_len, (r+1)*run_len).  Wave gw starts with run gw; further runs come from
     // an atomic queue, always grabbed one run ahead so the atomic's latency hides behind a whole run.  (The two
@@ -315,12 +314,13 @@ __global__ __launch_bounds__(256, WPS) void fir_direct_wave_kernel(const f2 *__r
     if (run < runs_total)
     {
         // ---- prologue: halo + first tile of the first run (bounds-checked path; once per wave) -----------------
-        fill_slow<G>(wl, lane, 0, HU + G::TILE_UNITS, in, hist, T, (int64_t)n0 + run * run_len * G::TILE_IN - G::HALO, N);
+        fill_slow<G>(wl, lane, 0, HU + G::TILE_UNITS, in, hist, T,
+                     (int64_t)n0 + ((run < n_long) ? run * run_len : (int64_t)n_long * run_len + (run - n_long)) * G::TILE_IN - G::HALO, N);
     }
     while (run < runs_total)
     {
-        const int64_t t_first = run * run_len;
-        const int64_t t_last = (t_first + run_len < tiles_total) ? t_first + run_len : tiles_total;
+        const int64_t t_first = (run < n_long) ? run * run_len : (int64_t)n_long * run_len + (run - n_long);
+        const int64_t t_last = (run < n_long) ? t_first + run_len : t_first + 1;
         if (lane == 0)
             ticket = atomicAdd(queue, 1u);                  // reservation for the run after this one
         have_ticket = true;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, WPS) void fir_direct_wave_kernel(const f2 *__r
             {
                 next_run = (int64_t)waves_total + (int64_t)__builtin_amdgcn_readfirstlane(ticket);
                 have_ticket = false;
-                t_next = next_run * run_len;
+                t_next = (next_run < n_long) ? next_run * run_len : (int64_t)n_long * run_len + (next_run - n_long);
             }
             const bool has_next = contiguous || (next_run < runs_total);
             const int64_t base_next = (int64_t)n0 + t_next * G::TILE_IN; // first sample of the next tile
@@ -696,7 +696,11 @@ static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
     const int64_t per_wave = (tiles + waves - 1) / waves;
     if (run_len > per_wave)
         run_len = per_wave;
-    const int64_t runs = (tiles + run_len - 1) / run_len;
+    // ~85 % of the tiles in runs of run_len (and at least one full run per wave), the tail tile by tile
+    int64_t n_long = (tiles * 85 / 100) / run_len;
+    if (n_long < waves)
+        n_long = (tiles / run_len < waves) ? tiles / run_len : waves;
+    const int64_t runs = n_long + (tiles - n_long * run_len);
     if (runs < waves)
     {
         blocks = (runs + 3) / 4;
@@ -707,7 +711,7 @@ static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
         return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, a.stream, reinterpret_cast<const f2 *>(a.in),
                        reinterpret_cast<f2 *>(a.out), a.taps, reinterpret_cast<const f2 *>(a.hist), a.N, a.n0, a.M,
-                       tiles, (int32_t)run_len, (int32_t)waves, (unsigned int *)a.queue,
+                       tiles, (int32_t)run_len, (int32_t)n_long, (int32_t)waves, (unsigned int *)a.queue,
                        (unsigned long long *)a.dbg);
     return hipGetLastError();
 }
@@ -724,9 +728,9 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             case 1: return launch_direct<255, 4, 8, 32, 256, false>(a);
             case 2: return launch_direct<255, 4, 8, 32, 128, true>(a);
             case 3: return launch_direct<255, 4, 8, 32, 256, true>(a);
-            case 4: return launch_wave<255, 4, 8, 32, 1>(a, 4);
+            case 4: return launch_wave<255, 4, 8, 32, 0>(a, 8);
             case 5: return launch_wave<255, 4, 8, 32, 0>(a, 4);
-            case 6: return launch_wave<255, 4, 8, 32, 3>(a, 4);
+            case 6: return launch_wave<255, 4, 8, 32, 0>(a, 2);
             case 7: return launch_wave<255, 4, 8, 32, 2>(a, 2);
             case 8: return launch_wave<255, 4, 8, 32, 2>(a, 8);
             case 9: return launch_wave<255, 4, 8, 32, 2>(a, 1);

@@ -144,3 +144,34 @@ def test_f32_models_within_tolerance(oracle, t, d):
     if t == 255 and d == 1:
         _, mx1 = oracle.err_metrics(oracle.fir_f32fma(h, x, d), ref)
         assert mx1 > mx
+
+
+def test_tapsplit_order_model_matches_a_python_restatement(oracle):
+    """Mode 3 of the float32 order model (tap-split kernel): lane q owns taps 4j+q, descending j, segments of 32 steps,
+    quad sums combined as (q0+q1)+(q2+q3) — restated here with numpy float32 scalars on a small case."""
+    rng = np.random.default_rng(3)
+    t, d, n = 77, 3, 200
+    h = rng.standard_normal(t).astype(np.float32)
+    x = rng.integers(-64, 64, 2 * n).astype(np.float32) / np.float32(8)
+    y = oracle.fir_f32fma(h, x, d, seg_mode=3, seg_len=32)
+    xc = x.reshape(-1, 2)
+    jn = (t + 3) // 4
+    out = []
+    for m in range(oracle.out_count(0, n, d)):
+        nn = m * d
+        lanes = []
+        for q in range(4):
+            tot, acc, have = np.zeros(2, np.float32), np.zeros(2, np.float32), False
+            for j in range(jn - 1, -1, -1):
+                k = 4 * j + q
+                if k < t and nn - k >= 0:
+                    # float32 fma: exact product in float64 (24+24 bits), one rounding of the sum to float32
+                    acc = (xc[nn - k].astype(np.float64) * np.float64(h[k]) + acc.astype(np.float64)).astype(np.float32)
+                if j % 32 == 0:
+                    tot = acc.copy() if not have else (tot + acc).astype(np.float32)
+                    have, acc = True, np.zeros(2, np.float32)
+            lanes.append(tot)
+        out.append(((lanes[0] + lanes[1]).astype(np.float32) + (lanes[2] + lanes[3]).astype(np.float32)).astype(np.float32))
+    assert np.array_equal(y.reshape(-1, 2), np.array(out, dtype=np.float32))
+    l2, mx = oracle.err_metrics(y, oracle.fir_f64(h, x, d))
+    assert l2 <= 2e-7 and mx <= 6e-7

@@ -196,7 +196,7 @@ def emit_function(f, name, lines, clobbers, meta, suffix=""):
 
 CONFIGS = [
     # (T, D, R, SEG, [(suffix, Q, U), ...])
-    (255, 4, 8, 32, [("", 4, 1), ("_q6", 6, 1), ("_b128", 2, 2), ("_b128q3", 3, 2)]),
+    (255, 4, 8, 32, [("", 4, 1), ("_b128", 2, 2)]),
     (255, 1, 8, 32, [("", 4, 1)]),
     (255, 1, 16, 32, [("", 3, 1)]),
     (127, 1, 8, 32, [("", 4, 1)]),
