@@ -63,11 +63,20 @@ enum
  * unity gain at the band centre.  Defaults used by the benchmarks: 0.15–0.25, Blackman. */
 uint8_t if_bpf_design(float *pfTaps, uint32_t ulTaps, double dLow, double dHigh, uint32_t ulWindow);
 
+/* Complex taps for channel selection (one-sided band-pass): low-pass prototype of two-sided bandwidth dBandwidth
+ * shifted to dCentre (both in cycles/sample, |dCentre| ≤ 0.5); pfTapsIQ receives ulTaps interleaved (re, im) pairs. */
+uint8_t if_bpf_design_complex(float *pfTapsIQ, uint32_t ulTaps, double dCentre, double dBandwidth, uint32_t ulWindow);
+
 /* ---- context -------------------------------------------------------------------------------------------------- */
 /* Copies the taps to the device, allocates history (and, for if_fir_process, staging buffers sized for
  * ullMaxSamples input samples per call).  lDevice = HIP device ordinal. */
 uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t ulTaps, uint32_t ulDecimation,
                     uint64_t ullMaxSamples, int32_t lDevice);
+/* Same with COMPLEX taps (ulTaps interleaved re,im pairs): y[n] = Σ g[k]·x[n-k].  Served by the overlap-save backend at
+ * the speed of real taps (its transfer function is complex anyway) and by the generic kernel; the unrolled direct and
+ * tap-split kernels take real taps only. */
+uint8_t if_fir_init_complex(if_fir_ctx_t **ppCtx, const float *pfTapsIQ, uint32_t ulTaps, uint32_t ulDecimation,
+                            uint64_t ullMaxSamples, int32_t lDevice);
 void if_fir_destroy(if_fir_ctx_t *pCtx);
 /* zero the history and the decimation phase */
 uint8_t if_fir_reset(if_fir_ctx_t *pCtx);

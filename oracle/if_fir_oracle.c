@@ -383,6 +383,112 @@ ORACLE_API uint64_t oracle_fir_c64_f32_omp(const float *pfTaps, uint32_t T, uint
     return M;
 }
 
+/* ------------------------------------------------------------------------------------------- */
+/* Complex taps (one-sided band-pass / channel selection): y[n] = Σ g[k]·x[n-k], g complex.     */
+/* pfTapsIQ holds T interleaved (re, im) float32 pairs.                                         */
+/* ------------------------------------------------------------------------------------------- */
+/* low-pass prototype of bandwidth dBandwidth (cycles/sample, two-sided) shifted to dCentre: g[k] = hlp[k]·e^{j2π·fc·(k-M)} */
+ORACLE_API int oracle_bpf_design_complex(float *pfTapsIQ, uint32_t ulTaps, double dCentre, double dBandwidth, uint32_t ulWindow)
+{
+    if (!pfTapsIQ || ulTaps < 3 || !(ulTaps & 1) || !(dBandwidth > 0.0) || !(dBandwidth <= 1.0) || !(fabs(dCentre) <= 0.5) || ulWindow > 3)
+        return 0;
+    const double M = (double)(ulTaps - 1) / 2.0, fc = 0.5 * dBandwidth;
+    double *g = (double *)malloc(sizeof(double) * ulTaps), gain = 0.0;
+    if (!g)
+        return 0;
+    for (uint32_t n = 0; n < ulTaps; n++)
+    {
+        const double t = (double)n - M, a = 2.0 * M_PI * (double)n / (double)(ulTaps - 1);
+        double w;
+        switch (ulWindow)
+        {
+        case 0: w = 1.0; break;
+        case 1: w = 0.54 - 0.46 * cos(a); break;
+        case 2: w = 0.5 - 0.5 * cos(a); break;
+        default: w = 0.42 - 0.5 * cos(a) + 0.08 * cos(2.0 * a); break;
+        }
+        g[n] = 2.0 * fc * oracle_sinc(2.0 * fc * t) * w;
+        gain += g[n];
+    }
+    for (uint32_t n = 0; n < ulTaps; n++)
+    {
+        const double t = (double)n - M, ph = 2.0 * M_PI * dCentre * t;
+        pfTapsIQ[2 * n] = (float)(g[n] / gain * cos(ph));
+        pfTapsIQ[2 * n + 1] = (float)(g[n] / gain * sin(ph));
+    }
+    free(g);
+    return 1;
+}
+
+ORACLE_API uint64_t oracle_fir_c64_ctaps_f64(const float *pfTapsIQ, uint32_t T, uint32_t D, const float *pfHist,
+                                            uint64_t ullConsumed, const float *pfIn, uint64_t N, double *pdOut)
+{
+    const uint64_t M = oracle_out_count(ullConsumed, N, D);
+    const int64_t n0 = (int64_t)((D - ullConsumed % D) % D);
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < (int64_t)M; m++)
+    {
+        const int64_t n = n0 + m * (int64_t)D;
+        double ar = 0.0, ai = 0.0;
+        for (uint32_t k = 0; k < T; k++)
+        {
+            float xr, xi;
+            oracle_fetch(pfHist, T, pfIn, n - (int64_t)k, &xr, &xi);
+            const double hr = pfTapsIQ[2 * k], hi = pfTapsIQ[2 * k + 1];
+            ar += (double)xr * hr - (double)xi * hi;
+            ai += (double)xr * hi + (double)xi * hr;
+        }
+        pdOut[2 * m] = ar;
+        pdOut[2 * m + 1] = ai;
+    }
+    return M;
+}
+
+/* float32 order model of the generic kernel with complex taps: descending k, segments of L taps [sL,(s+1)L) added  */
+/* as they complete; per tap  re = fma(-xi, hi, fma(xr, hr, re)),  im = fma(xi, hr, fma(xr, hi, im)).                 */
+ORACLE_API uint64_t oracle_fir_c64_ctaps_f32fma(const float *pfTapsIQ, uint32_t T, uint32_t D, const float *pfHist,
+                                               uint64_t ullConsumed, const float *pfIn, uint64_t N, float *pfOut, uint32_t L)
+{
+    const uint64_t M = oracle_out_count(ullConsumed, N, D);
+    const int64_t n0 = (int64_t)((D - ullConsumed % D) % D);
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < (int64_t)M; m++)
+    {
+        const int64_t n = n0 + m * (int64_t)D;
+        float tr = 0.0f, ti = 0.0f, ar = 0.0f, ai = 0.0f;
+        const int64_t top = ((int64_t)T - 1) / L;
+        for (int64_t k = (int64_t)T - 1; k >= 0; k--)
+        {
+            float xr, xi;
+            oracle_fetch(pfHist, T, pfIn, n - k, &xr, &xi);
+            const float hr = pfTapsIQ[2 * k], hi = pfTapsIQ[2 * k + 1];
+            if (k == (int64_t)T - 1 || k % L == L - 1)
+            {
+                ar = 0.0f;
+                ai = 0.0f;
+            }
+            ar = fmaf(-xi, hi, fmaf(xr, hr, ar));
+            ai = fmaf(xi, hr, fmaf(xr, hi, ai));
+            if (k % L == 0)
+            {
+                if (k / L == top)
+                {
+                    tr = ar;
+                    ti = ai;
+                }
+                else
+                {
+                    tr += ar;
+                    ti += ai;
+                }
+            }
+        }
+        pfOut[2 * m] = tr;
+        pfOut[2 * m + 1] = ti;
+    }
+    return M;
+}
+
 ORACLE_API int32_t oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -45,6 +45,12 @@ def _bind(lib):
     lib.oracle_fir_c64_f32fma.restype = u64
     lib.oracle_fir_c64_f32_omp.argtypes = [_f32p, u32, u32, _f32p, u64, _f32p, i32]
     lib.oracle_fir_c64_f32_omp.restype = u64
+    lib.oracle_bpf_design_complex.argtypes = [_f32p, u32, ctypes.c_double, ctypes.c_double, u32]
+    lib.oracle_bpf_design_complex.restype = ctypes.c_int
+    lib.oracle_fir_c64_ctaps_f64.argtypes = [_f32p, u32, u32, _f32p, u64, _f32p, u64, _f64p]
+    lib.oracle_fir_c64_ctaps_f64.restype = u64
+    lib.oracle_fir_c64_ctaps_f32fma.argtypes = [_f32p, u32, u32, _f32p, u64, _f32p, u64, _f32p, u32]
+    lib.oracle_fir_c64_ctaps_f32fma.restype = u64
     lib.oracle_max_threads.restype = i32
     lib.oracle_err_metrics.argtypes = [_f32p, _f64p, u64, _f64p]
     del u8
@@ -187,6 +193,37 @@ def fir_f32_omp(taps, x, decim=1, threads=0, handle=None):
     m = (n + decim - 1) // decim
     y = np.empty(2 * m, dtype=np.float32)
     (handle or lib()).oracle_fir_c64_f32_omp(_p32(taps), t, decim, _p32(buf), n, _p32(y), threads)
+    return y
+
+
+def bpf_design_complex(taps, centre=0.2, bandwidth=0.1, window="blackman"):
+    """Complex taps: low-pass prototype of two-sided bandwidth `bandwidth` shifted to `centre` (interleaved re,im)."""
+    g = np.zeros(2 * taps, dtype=np.float32)
+    if not lib().oracle_bpf_design_complex(_p32(g), taps, float(centre), float(bandwidth), WINDOWS[window]):
+        raise ValueError("oracle_bpf_design_complex rejected the arguments")
+    return g
+
+
+def fir_ctaps_f64(ctaps, x, decim=1, hist=None, consumed=0):
+    """float64 oracle with complex taps (interleaved re,im float32)."""
+    ctaps = _iq(ctaps)
+    x = _iq(x)
+    n, t = x.size // 2, ctaps.size // 2
+    hist = None if hist is None else _iq(hist)
+    m = out_count(consumed, n, decim)
+    y = np.empty(2 * m, dtype=np.float64)
+    assert lib().oracle_fir_c64_ctaps_f64(_p32(ctaps), t, decim, _p32(hist), consumed, _p32(x), n, _p64(y)) == m
+    return y
+
+
+def fir_ctaps_f32fma(ctaps, x, decim=1, hist=None, consumed=0, seg_len=32):
+    ctaps = _iq(ctaps)
+    x = _iq(x)
+    n, t = x.size // 2, ctaps.size // 2
+    hist = None if hist is None else _iq(hist)
+    m = out_count(consumed, n, decim)
+    y = np.empty(2 * m, dtype=np.float32)
+    assert lib().oracle_fir_c64_ctaps_f32fma(_p32(ctaps), t, decim, _p32(hist), consumed, _p32(x), n, _p32(y), seg_len) == m
     return y
 
 

@@ -79,3 +79,51 @@ uint8_t if_bpf_design(float *pfTaps, uint32_t ulTaps, double dLow, double dHigh,
 
     return 1;
 }
+
+/*
+ * Complex taps for channel selection: a windowed-sinc low-pass prototype of two-sided bandwidth dBandwidth
+ * (cycles/sample) shifted to dCentre, g[k] = hlp[k] * exp(j*2*pi*dCentre*(k - M)), unity gain at dCentre.
+ * pfTapsIQ receives ulTaps interleaved (re, im) float32 pairs.  BUILD-DEFINED like if_bpf_design().
+ */
+uint8_t if_bpf_design_complex(float *pfTapsIQ, uint32_t ulTaps, double dCentre, double dBandwidth, uint32_t ulWindow)
+{
+    if (!pfTapsIQ || ulTaps < 3 || !(ulTaps & 1) || ulTaps > IF_FIR_MAX_TAPS)
+        return 0;
+    if (!(dBandwidth > 0.0) || !(dBandwidth <= 1.0) || !(fabs(dCentre) <= 0.5) || ulWindow > IF_BPF_WINDOW_BLACKMAN)
+        return 0;
+
+    double *pdProto = (double *)malloc(sizeof(double) * ulTaps);
+
+    if (!pdProto)
+        return 0;
+
+    const double dMid = (double)(ulTaps - 1) / 2.0;
+    const double dCut = 0.5 * dBandwidth;
+    double dGain = 0.0;
+
+    for (uint32_t i = 0; i < ulTaps; i++)
+    {
+        const double dT = (double)i - dMid;
+
+        pdProto[i] = 2.0 * dCut * bpf_sinc(2.0 * dCut * dT) * bpf_window(ulWindow, i, ulTaps);
+        dGain += pdProto[i];
+    }
+
+    if (!(fabs(dGain) > 0.0))
+    {
+        free(pdProto);
+        return 0;
+    }
+
+    for (uint32_t i = 0; i < ulTaps; i++)
+    {
+        const double dPhase = 2.0 * M_PI * dCentre * ((double)i - dMid);
+
+        pfTapsIQ[2 * i + 0] = (float)(pdProto[i] / dGain * cos(dPhase));
+        pfTapsIQ[2 * i + 1] = (float)(pdProto[i] / dGain * sin(dPhase));
+    }
+
+    free(pdProto);
+
+    return 1;
+}

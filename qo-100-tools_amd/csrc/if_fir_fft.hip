@@ -682,7 +682,7 @@ hipError_t launch_fft(const LaunchArgs &a)
 //   [32 KB, 64 KB)  hp [(i*16+k2)*64 + lane]   = FFT(taps)[(4*(lane/16)+i) + 16*(lane%16) + 256*k2] / 4096
 //   [64 KB, 66 KB)  tw2[k1*16 + n2]            = W256^(n2*k1)
 //   [66 KB, 82 KB)  twd, twe: twiddles of the decimate-by-4 1024-point inverse
-void fft_build_tables(const float *taps, int T, float *tables /* FFT_TABLE_FLOATS floats */)
+void fft_build_tables(const float *taps, int T, int ctaps, float *tables /* FFT_TABLE_FLOATS floats */)
 {
     const double PI2 = 6.283185307179586476925286766559;
     float *tw1 = tables, *hp = tables + 2 * 4096, *tw2 = tables + 4 * 4096;
@@ -738,8 +738,10 @@ void fft_build_tables(const float *taps, int T, float *tables /* FFT_TABLE_FLOAT
                 for (int n = 0; n < T; n++)
                 {
                     const int e = (int)(((int64_t)k * n) & 4095);
-                    re += (double)taps[n] * ct[e];
-                    im += (double)taps[n] * st[e];
+                    const double hr = ctaps ? (double)taps[2 * n] : (double)taps[n];
+                    const double hi = ctaps ? (double)taps[2 * n + 1] : 0.0;
+                    re += hr * ct[e] - hi * st[e];
+                    im += hr * st[e] + hi * ct[e];
                 }
                 hp[2 * ((i * 16 + k2) * 64 + lane) + 0] = (float)(re / 4096.0);
                 hp[2 * ((i * 16 + k2) * 64 + lane) + 1] = (float)(im / 4096.0);

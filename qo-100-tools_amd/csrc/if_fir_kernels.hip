@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void fir_tapsplit_kernel(const f2 *__restrict_
 // (uniform index), samples straight from global/L2 (neighbouring lanes share lines).  Same summation order
 // as the fast kernels (descending k, segments of SEG).  Correctness fallback, not a performance path.
 // --------------------------------------------------------------------------------------------------------------
-template <int SEG>
+template <int SEG, bool CTAPS>
 __global__ __launch_bounds__(256) void fir_generic_kernel(const f2 *__restrict__ in, f2 *__restrict__ out,
                                                          const float *__restrict__ taps,
                                                          const f2 *__restrict__ hist, int T, int D, int64_t N,
@@ -575,10 +575,22 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const f2 *__restrict__
     const int top = (T - 1) / SEG;
     for (int k = T - 1; k >= 0; k--)
     {
-        const float h = taps[k];
         const f2 s = fetch_sample(in, hist, T, n - k, N);
         const bool first = (k == T - 1) || (k % SEG == SEG - 1);
-        acc = __builtin_elementwise_fma(s, (f2){h, h}, first ? (f2){0.f, 0.f} : acc);
+        if (first)
+            acc = (f2){0.f, 0.f};
+        if constexpr (CTAPS)
+        {
+            // complex tap (hr, hi): re = fma(-xi, hi, fma(xr, hr, re)), im = fma(xi, hr, fma(xr, hi, im))
+            const float hr = taps[2 * k], hi = taps[2 * k + 1];
+            acc = __builtin_elementwise_fma((f2){-s.y, s.y}, (f2){hi, hr},
+                                            __builtin_elementwise_fma((f2){s.x, s.x}, (f2){hr, hi}, acc));
+        }
+        else
+        {
+            const float h = taps[k];
+            acc = __builtin_elementwise_fma(s, (f2){h, h}, acc);
+        }
         if (k % SEG == 0)
             tot = (k / SEG == top) ? acc : tot + acc;
     }
@@ -811,9 +823,14 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
         const int64_t blocks = (a.M + 255) / 256;
         if (blocks > 0x7fffffffLL)
             return hipErrorInvalidValue;
-        hipLaunchKernelGGL(fir_generic_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, a.stream,
-                           reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,
-                           reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M);
+        if (a.ctaps)
+            hipLaunchKernelGGL((fir_generic_kernel<32, true>), dim3((unsigned)blocks), dim3(256), 0, a.stream,
+                               reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,
+                               reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M);
+        else
+            hipLaunchKernelGGL((fir_generic_kernel<32, false>), dim3((unsigned)blocks), dim3(256), 0, a.stream,
+                               reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,
+                               reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M);
         return hipGetLastError();
     }
     return hipErrorInvalidConfiguration;

@@ -23,6 +23,7 @@ struct if_fir_ctx
     hipStream_t own_stream;
     hipStream_t stream;
     int T, D;
+    int ctaps; // taps are complex (interleaved re,im)
     uint32_t backend_req;
     uint32_t backend;
     int variant;
@@ -71,13 +72,17 @@ static uint32_t resolve_backend(const if_fir_ctx *ctx, uint32_t req)
 {
     if (req != IF_FIR_BACKEND_AUTO)
         return req;
-    if (if_fir::fft_supported(ctx->T, ctx->D) && ctx->T >= 32)
+    if (if_fir::fft_supported(ctx->T, ctx->D) && (ctx->T >= 32 || ctx->ctaps))
         return IF_FIR_BACKEND_HIP_FFT;
+    if (ctx->ctaps)
+        return IF_FIR_BACKEND_HIP_GENERIC;
     return if_fir::direct_supported(ctx->T, ctx->D) ? IF_FIR_BACKEND_HIP_DIRECT : IF_FIR_BACKEND_HIP_TAPSPLIT;
 }
 
 static bool backend_ok(const if_fir_ctx *ctx, uint32_t b)
 {
+    if (ctx->ctaps && b != IF_FIR_BACKEND_HIP_FFT && b != IF_FIR_BACKEND_HIP_GENERIC)
+        return false; // complex taps: overlap-save and generic kernels only
     switch (b)
     {
     case IF_FIR_BACKEND_HIP_DIRECT:
@@ -103,7 +108,7 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
         set_err(ctx, "overlap-save tables: out of host memory");
         return 0;
     }
-    if_fir::fft_build_tables(ctx->h_taps, ctx->T, tab);
+    if_fir::fft_build_tables(ctx->h_taps, ctx->T, ctx->ctaps, tab);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
@@ -128,8 +133,8 @@ static void tone_table(float *t)
     }
 }
 
-IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t ulTaps, uint32_t ulDecimation,
-                               uint64_t ullMaxSamples, int32_t lDevice)
+static uint8_t init_common(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t ulTaps, uint32_t ulDecimation,
+                           uint64_t ullMaxSamples, int32_t lDevice, int ctaps)
 {
     if (ppCtx)
         *ppCtx = nullptr;
@@ -144,10 +149,11 @@ IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32
                 IF_FIR_MAX_DECIMATION, ulTaps, ulDecimation);
         return 0;
     }
-    for (uint32_t i = 0; i < ulTaps; i++)
+    const uint32_t tap_floats = ctaps ? 2 * ulTaps : ulTaps;
+    for (uint32_t i = 0; i < tap_floats; i++)
         if (!std::isfinite(pfTaps[i]))
         {
-            set_err(nullptr, "if_fir_init: tap %u is not finite", i);
+            set_err(nullptr, "if_fir_init: tap %u is not finite", ctaps ? i / 2 : i);
             return 0;
         }
     int ndev = 0;
@@ -173,16 +179,17 @@ IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32
     ctx->device = lDevice;
     ctx->T = (int)ulTaps;
     ctx->D = (int)ulDecimation;
+    ctx->ctaps = ctaps;
     ctx->max_samples = ullMaxSamples;
     tone_table(ctx->tone);
-    ctx->h_taps = (float *)malloc(sizeof(float) * ulTaps);
+    ctx->h_taps = (float *)malloc(sizeof(float) * tap_floats);
     if (!ctx->h_taps)
     {
         set_err(nullptr, "if_fir_init: out of host memory");
         delete ctx;
         return 0;
     }
-    memcpy(ctx->h_taps, pfTaps, sizeof(float) * ulTaps);
+    memcpy(ctx->h_taps, pfTaps, sizeof(float) * tap_floats);
 
 #define INIT_TRY(call)                                                                               \
     do                                                                                               \
@@ -204,10 +211,10 @@ IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32
     INIT_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     // taps are fetched in whole 16-float blocks by s_load_dwordx16: pad the device copy with zeros to a multiple of 64
-    const size_t taps_padded = ((size_t)ulTaps + 63) / 64 * 64;
+    const size_t taps_padded = ((size_t)tap_floats + 63) / 64 * 64;
     INIT_TRY(hipMalloc((void **)&ctx->d_taps, sizeof(float) * taps_padded));
     INIT_TRY(hipMemset(ctx->d_taps, 0, sizeof(float) * taps_padded));
-    INIT_TRY(hipMemcpy(ctx->d_taps, pfTaps, sizeof(float) * ulTaps, hipMemcpyHostToDevice));
+    INIT_TRY(hipMemcpy(ctx->d_taps, pfTaps, sizeof(float) * tap_floats, hipMemcpyHostToDevice));
     INIT_TRY(hipMalloc(&ctx->d_queue, 16));
     INIT_TRY(hipMemset(ctx->d_queue, 0, 16));
     const size_t hist_bytes = 8 * (size_t)(ulTaps > 1 ? ulTaps - 1 : 1);
@@ -230,6 +237,18 @@ IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32
     ctx->err[0] = 0;
     *ppCtx = ctx;
     return 1;
+}
+
+IF_FIR_API uint8_t if_fir_init(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t ulTaps, uint32_t ulDecimation,
+                               uint64_t ullMaxSamples, int32_t lDevice)
+{
+    return init_common(ppCtx, pfTaps, ulTaps, ulDecimation, ullMaxSamples, lDevice, 0);
+}
+
+IF_FIR_API uint8_t if_fir_init_complex(if_fir_ctx_t **ppCtx, const float *pfTapsIQ, uint32_t ulTaps,
+                                       uint32_t ulDecimation, uint64_t ullMaxSamples, int32_t lDevice)
+{
+    return init_common(ppCtx, pfTapsIQ, ulTaps, ulDecimation, ullMaxSamples, lDevice, 1);
 }
 
 IF_FIR_API void if_fir_destroy(if_fir_ctx_t *pCtx)
@@ -368,6 +387,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.hist = ctx->d_hist[ctx->hist_cur];
     a.T = ctx->T;
     a.D = ctx->D;
+    a.ctaps = ctx->ctaps;
     a.N = (int64_t)n;
     a.n0 = (int32_t)n0;
     a.M = (int64_t)m;

@@ -13,7 +13,7 @@ WINDOW_RECT, WINDOW_HAMMING, WINDOW_HANN, WINDOW_BLACKMAN = range(4)
 
 # every symbol include/if_fir.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "if_bpf_design", "if_fir_init", "if_fir_destroy", "if_fir_reset", "if_fir_set_backend", "if_fir_get_backend",
+    "if_bpf_design", "if_bpf_design_complex", "if_fir_init", "if_fir_init_complex", "if_fir_destroy", "if_fir_reset", "if_fir_set_backend", "if_fir_get_backend",
     "if_fir_set_tuning", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
@@ -42,6 +42,10 @@ def lib():
     L.if_bpf_design.restype = u8
     L.if_fir_init.argtypes = [ctypes.POINTER(vp), f32p, u32, u32, u64, i32]
     L.if_fir_init.restype = u8
+    L.if_fir_init_complex.argtypes = [ctypes.POINTER(vp), f32p, u32, u32, u64, i32]
+    L.if_fir_init_complex.restype = u8
+    L.if_bpf_design_complex.argtypes = [f32p, u32, ctypes.c_double, ctypes.c_double, u32]
+    L.if_bpf_design_complex.restype = u8
     L.if_fir_destroy.argtypes = [vp]
     L.if_fir_destroy.restype = None
     L.if_fir_reset.argtypes = [vp]
@@ -96,16 +100,32 @@ def bpf_design(taps, f_low=0.15, f_high=0.25, window=WINDOW_BLACKMAN):
     return h
 
 
+def bpf_design_complex(taps, centre=0.2, bandwidth=0.1, window=WINDOW_BLACKMAN):
+    """if_bpf_design_complex(): channel-selection taps, interleaved (re, im) float32."""
+    g = np.zeros(2 * max(int(taps), 0), dtype=np.float32)
+    if not lib().if_bpf_design_complex(_f32p(g), int(taps), float(centre), float(bandwidth), int(window)):
+        raise IfFirError("if_bpf_design_complex rejected taps=%r centre=%r bandwidth=%r" % (taps, centre, bandwidth))
+    return g
+
+
 class IfFir:
     """One if_fir_ctx_t.  Methods mirror the C entry points."""
 
-    def __init__(self, taps, decimation=1, max_samples=1 << 20, device=0, backend=None):
+    def __init__(self, taps, decimation=1, max_samples=1 << 20, device=0, backend=None, complex_taps=False):
+        taps = np.asarray(taps)
+        if np.iscomplexobj(taps):
+            taps = np.ascontiguousarray(taps.astype(np.complex64)).view(np.float32)
+            complex_taps = True
         taps = np.ascontiguousarray(taps, dtype=np.float32)
         self._ctx = ctypes.c_void_p()
         self.taps = taps
         self.decimation = int(decimation)
-        ok = lib().if_fir_init(ctypes.byref(self._ctx), _f32p(taps), taps.size, self.decimation, int(max_samples),
-                               int(device))
+        if complex_taps:
+            ok = lib().if_fir_init_complex(ctypes.byref(self._ctx), _f32p(taps), taps.size // 2, self.decimation,
+                                           int(max_samples), int(device))
+        else:
+            ok = lib().if_fir_init(ctypes.byref(self._ctx), _f32p(taps), taps.size, self.decimation,
+                                   int(max_samples), int(device))
         if not ok:
             self._ctx = ctypes.c_void_p()
             raise IfFirError(lib().if_fir_last_error(None).decode())

@@ -8,6 +8,7 @@ Contents (all little-endian):
   taps_{127,255,1023}      float32   scipy.signal.firwin(T,[0.3,0.5],window='blackman',pass_zero=False,scale=True)
   x                        float32   4096 IQ samples, interleaved: SPEC §5 generator restated with numpy (channel 0)
   y_T{T}_D{D}              float64   interleaved I/Q:  scipy.signal.upfirdn(h, x, down=D)[:ceil(N/D)]
+  ctaps_255, yc_T255_D{1,4}  complex taps: scipy low-pass (bandwidth 0.1) shifted to +0.2, outputs by upfirdn
   xr / yr_T127             float32/float64   real-sample case (BASELINE configs[0] shape, 4096 samples): lfilter
 """
 import os
@@ -51,6 +52,13 @@ def main():
         for dec in (1, 4):
             y = ss.upfirdn(h.astype(np.float64), xc, down=dec)[:(n + dec - 1) // dec]
             d["y_T%d_D%d" % (t, dec)] = np.ascontiguousarray(y).view(np.float64)
+    # complex taps (channel selection): scipy low-pass prototype (two-sided bandwidth 0.1) shifted to +0.2 cycles/sample
+    hl = ss.firwin(255, 0.1, window="blackman", scale=True)
+    gc = (hl * np.exp(2j * np.pi * 0.2 * (np.arange(255) - 127))).astype(np.complex64)
+    d["ctaps_255"] = gc.view(np.float32).copy()
+    for dec in (1, 4):
+        y = ss.upfirdn(gc.astype(np.complex128), xc, down=dec)[:(n + dec - 1) // dec]
+        d["yc_T255_D%d" % dec] = np.ascontiguousarray(y).view(np.float64)
     xr = x[0::2].copy()
     d["xr"] = xr
     d["yr_T127"] = ss.lfilter(d["taps_127"].astype(np.float64), 1.0, xr.astype(np.float64))

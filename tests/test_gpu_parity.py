@@ -325,3 +325,40 @@ def test_tapsplit_kernel_vs_oracle(fir, oracle, t, d):
         cuts = [0, 1, 2, 77, 255, 256, 4097, 9000, 20_001, n]
         parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
         assert np.array_equal(np.concatenate(parts), model)
+
+
+@pytest.mark.parametrize("t,d", [(255, 4), (255, 1), (127, 1), (1023, 4), (31, 3), (5, 1)])
+def test_complex_taps(fir, oracle, t, d):
+    """Complex taps (channel selection): overlap-save backend within SPEC tolerance of the float64 oracle; generic
+    kernel bit-exact against its order model; streaming pieces; the real-tap-only backends refuse."""
+    rng = np.random.default_rng(t * 3 + d)
+    g = fir.bpf_design_complex(t, 0.2, 0.1) if t >= 31 else rng.standard_normal(2 * t).astype(np.float32)
+    n = 40_009
+    x = np.concatenate([oracle.synth_iq(n // 2, 12), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
+    ref = oracle.fir_ctaps_f64(g, x, d)
+    with fir.IfFir(g, d, n, complex_taps=True) as f:
+        expect_fft = d in (1, 4)
+        assert f.get_backend() == (fir.BACKEND_HIP_FFT if expect_fft else fir.BACKEND_HIP_GENERIC)
+        y = f.process(x)
+        l2, mx = oracle.err_metrics(y, ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        f.reset()
+        cuts = [0, 3, 1000, 1001, 8191, 20_000, n]
+        parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
+        assert l2 <= TOL and mx <= TOL
+        f.set_backend(fir.BACKEND_HIP_GENERIC)
+        f.reset()
+        yg = f.process(x)
+        assert np.array_equal(yg, oracle.fir_ctaps_f32fma(g, x, d))
+        for b in (fir.BACKEND_HIP_DIRECT, fir.BACKEND_HIP_TAPSPLIT):
+            with pytest.raises(fir.IfFirError):
+                f.set_backend(b)
+
+
+def test_complex_taps_golden(fir, oracle):
+    gold = np.load(GOLD)
+    for d in (1, 4):
+        with fir.IfFir(gold["ctaps_255"], d, 4096, complex_taps=True) as f:
+            l2, mx = oracle.err_metrics(f.process(gold["x"]), gold["yc_T255_D%d" % d])
+        assert l2 <= TOL and mx <= TOL

@@ -37,6 +37,17 @@ def test_c_designer_matches_oracle_and_golden(fir, oracle, t):
         assert np.array_equal(fir.bpf_design(t, 0.1, 0.3, win), oracle.bpf_design(t, 0.1, 0.3, name))
 
 
+def test_c_complex_designer_matches_oracle_and_golden(fir, oracle):
+    g = fir.bpf_design_complex(255, 0.2, 0.1)
+    assert np.array_equal(g, oracle.bpf_design_complex(255, 0.2, 0.1))
+    assert np.array_equal(g, np.load(GOLD)["ctaps_255"])
+    assert np.array_equal(fir.bpf_design_complex(127, -0.3, 0.05, fir.WINDOW_HAMMING),
+                          oracle.bpf_design_complex(127, -0.3, 0.05, "hamming"))
+    for args in [(128, 0.2, 0.1), (255, 0.6, 0.1), (255, 0.2, 0.0), (255, 0.2, 1.5)]:
+        with pytest.raises(fir.IfFirError):
+            fir.bpf_design_complex(*args)
+
+
 def test_c_designer_rejects_bad_arguments(fir):
     for args in [(128,), (1,), (0,), (4097,), (127, 0.3, 0.2), (127, 0.1, 0.6), (127, -0.1, 0.2), (127, 0.1, 0.2, 9)]:
         with pytest.raises(fir.IfFirError):

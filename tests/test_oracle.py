@@ -175,3 +175,24 @@ def test_tapsplit_order_model_matches_a_python_restatement(oracle):
     assert np.array_equal(y.reshape(-1, 2), np.array(out, dtype=np.float32))
     l2, mx = oracle.err_metrics(y, oracle.fir_f64(h, x, d))
     assert l2 <= 2e-7 and mx <= 6e-7
+
+
+def test_complex_taps_oracle_matches_golden(oracle, gold):
+    g = oracle.bpf_design_complex(255, 0.2, 0.1)
+    assert np.array_equal(g, gold["ctaps_255"])                 # scipy-made fixture, bit-exact in float32
+    for d in (1, 4):
+        y = oracle.fir_ctaps_f64(g, gold["x"], d)
+        assert np.max(np.abs(y - gold["yc_T255_D%d" % d])) <= 4e-15
+        l2, mx = oracle.err_metrics(oracle.fir_ctaps_f32fma(g, gold["x"], d), y)
+        assert l2 <= 2e-7 and mx <= 6e-7
+    # real taps written as complex taps with zero imaginary part give the real-tap oracle exactly
+    h = oracle.bpf_design(127)
+    hc = np.zeros(254, dtype=np.float32)
+    hc[0::2] = h
+    assert np.array_equal(oracle.fir_ctaps_f64(hc, gold["x"], 3), oracle.fir_f64(h, gold["x"], 3))
+    # the stop-band tone at +0.4 and the mirror image at -0.2 are rejected, the +0.2 tone passes with unit gain
+    n = np.arange(4096)
+    for f, expect in [(0.2, 1.0), (-0.2, 0.0), (0.4, 0.0)]:
+        tone = np.exp(2j * np.pi * f * n).astype(np.complex64)
+        y = oracle.fir_ctaps_f64(g, tone, 1).view(np.complex128)[300:]
+        assert abs(np.mean(np.abs(y)) - expect) < 2e-4
