@@ -281,7 +281,10 @@ def main():
                          "note": "HIP events on the launch stream around the timed steps / steps (includes the "
                                  "history-update kernel and the queue memset)"},
             "valu": {"achieved": round(achieved_tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved_tf / VALU_PEAK_TFLOPS, 4)},
+                     "frac": round(achieved_tf / VALU_PEAK_TFLOPS, 4),
+                     "note": ("direct-form-EQUIVALENT rate (4*taps/decimation flop per input sample / time); the "
+                              "overlap-save kernel executes ~8x fewer flops, so this is not a VALU utilisation")
+                     if f.get_backend() == fir.BACKEND_HIP_FFT else "executed FP32 VALU flops / time"},
             "parity": parity,
         }
         if extra:

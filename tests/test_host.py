@@ -65,3 +65,13 @@ def test_init_argument_errors_and_no_cpu_fallback(fir):
     if not torch.cuda.is_available():
         with pytest.raises(fir.IfFirError, match="no HIP device"):
             fir.IfFir(taps)   # must fail loudly, never fall back to a CPU path
+
+
+def test_generated_walk_header_is_current():
+    """csrc/generated/if_fir_walk_gen.h is the committed output of tools/gen_walk.py (regenerating changes nothing)."""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(), "walk.h")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_walk.py"), "--out", out])
+    committed = open(os.path.join(ROOT, "qo-100-tools_amd", "csrc", "generated", "if_fir_walk_gen.h")).read()
+    assert open(out).read() == committed
