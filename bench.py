@@ -35,13 +35,14 @@ WORKLOADS = {
     "fir127_2p26": (127, 1, 26, "127-tap complex-IQ FIR, one channel per GPU, 2^26 IQ samples (BASELINE configs[1])"),
     "fir255_2p28": (255, 1, 28, "255-tap complex-IQ FIR, no decimation, one channel per GPU, 2^28 IQ samples"),
     "fir255_dec4_2p24": (255, 4, 24, "255-tap + decimate-by-4, 2^24 IQ samples (quick check size)"),
+    "fir255_dec4_i16_2p28": (255, 4, 28, "255-tap FIR + decimate-by-4, int16 IQ input front-end (SURVEY §8f-1), 2^28 samples"),
     "fir2047_dec8_2p26": (2047, 8, 26, "2047-tap FIR, decimate-by-8, 2^26 IQ samples (tap-split kernel territory)"),
     "fir1023_2p28": (1023, 1, 28, "1023-tap complex-IQ FIR, one channel per GPU, 2^28 IQ samples (BASELINE configs[4])"),
 }
 
 
-def algorithmic_bytes_per_sample(decim):
-    return 8.0 + 8.0 / decim          # read 8 B per input sample, write 8/D
+def algorithmic_bytes_per_sample(decim, in_bytes=8.0):
+    return in_bytes + 8.0 / decim     # read 8 B (4 B for int16 input) per input sample, write 8/D
 
 
 def algorithmic_flops_per_sample(taps, decim):
@@ -129,6 +130,8 @@ def main():
     fir = pkg.if_fir
     taps_n, decim, log2n, desc = WORKLOADS[args.workload]
     n = 1 << log2n
+    i16 = "_i16_" in args.workload
+    in_bytes = 4.0 if i16 else 8.0
     taps = fir.bpf_design(taps_n)
     backend_ids = {"auto": fir.BACKEND_AUTO, "direct": fir.BACKEND_HIP_DIRECT, "fft": fir.BACKEND_HIP_FFT,
                    "generic": fir.BACKEND_HIP_GENERIC}
@@ -144,6 +147,17 @@ def main():
     channel = rank                      # weak scaling: one independent transponder channel per GPU
     f.synth_device(x.data_ptr(), 0, n, channel)
     torch.cuda.synchronize()
+    if i16:
+        # int16 front-end: quantise the synthetic stream (full scale = 2.0) on the device, filter the int16 buffer
+        f.set_input_format(fir.INPUT_I16)
+        xq = torch.empty(2 * n, dtype=torch.int16, device=dev)
+        step_q = 1 << 24
+        for a in range(0, 2 * n, step_q):
+            xq[a:a + step_q] = torch.clamp(torch.round(x[a:a + step_q] * 16384.0), -32768, 32767).to(torch.int16)
+        x_f32_head = x[:2 * (1 << 16)].clone()
+        del x
+        x = xq
+        torch.cuda.synchronize()
 
     # every step continues the stream (history + phase carried): identical work per step, no reset memset
     def step_stream():
@@ -176,7 +190,7 @@ def main():
     extra = {}
     names = {1: "hip_direct", 2: "hip_tapsplit", 3: "hip_generic", 4: "hip_fft"}
     if rank == 0 and args.backend == "auto" and f.get_backend() == fir.BACKEND_HIP_FFT and taps_n in (127, 255) \
-            and decim in (1, 4):
+            and decim in (1, 4) and not i16:
         # the north_star's direct-form MAC kernel, timed beside the default overlap-save path (same buffers, same
         # stream; not part of `value`)
         f.set_backend(fir.BACKEND_HIP_DIRECT)
@@ -232,7 +246,7 @@ def main():
     if rank == 0:
         ms_per_step = wall_max / args.steps * 1e3
         value = world * n / (wall_max / args.steps) / 1e6
-        bytes_per_launch = algorithmic_bytes_per_sample(decim) * n
+        bytes_per_launch = algorithmic_bytes_per_sample(decim, in_bytes) * n
         flops_per_launch = algorithmic_flops_per_sample(taps_n, decim) * n
         achieved_gbs = bytes_per_launch / (dev_ms_max * 1e-3) / 1e9
         achieved_tf = flops_per_launch / (dev_ms_max * 1e-3) / 1e12
@@ -250,6 +264,8 @@ def main():
         oracle = graft.load_oracle()
         f2 = fir.IfFir(taps, decim, 0, device=local_rank, backend=backend_ids[args.backend])
         f2.set_stream(stream.cuda_stream)
+        if i16:
+            f2.set_input_format(fir.INPUT_I16)
         if args.variant is not None:
             f2.set_tuning(args.variant)
         head = 1 << 16
@@ -257,6 +273,8 @@ def main():
         f2.process_device(x.data_ptr(), yh.data_ptr(), head)
         torch.cuda.synchronize()
         xh = x[:2 * head].cpu().numpy()
+        if i16:
+            xh = xh.astype(np.float32) * np.float32(2.0 ** -15)
         l2, mx = oracle.err_metrics(yh.cpu().numpy(), oracle.fir_f64(taps, xh, decim))
         parity = {"rel_l2_vs_f64_oracle": l2, "rel_max_vs_f64_oracle": mx, "tolerance": 1e-6,
                   "window": "first 2^16 input samples"}

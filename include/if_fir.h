@@ -49,6 +49,13 @@ enum
     IF_FIR_BACKEND_HIP_FFT = 4      /* overlap-save, wave-private 4096-point FFT (T ≤ 1025, D = 1 or 4); AUTO's pick */
 };
 
+/* input sample formats (if_fir_set_input_format) */
+enum
+{
+    IF_FIR_INPUT_F32 = 0, /* interleaved float32 I,Q (8 bytes per sample), the default                         */
+    IF_FIR_INPUT_I16 = 1  /* interleaved int16 I,Q (4 bytes per sample), value = int16 * 2^-15  */
+};
+
 /* window ids for if_bpf_design */
 enum
 {
@@ -82,6 +89,9 @@ void if_fir_destroy(if_fir_ctx_t *pCtx);
 uint8_t if_fir_reset(if_fir_ctx_t *pCtx);
 uint8_t if_fir_set_backend(if_fir_ctx_t *pCtx, uint32_t ulBackend);
 uint32_t if_fir_get_backend(const if_fir_ctx_t *pCtx); /* the resolved (non-AUTO) backend */
+/* Input sample format: IF_FIR_INPUT_F32 (default) or IF_FIR_INPUT_I16 (pfIQIn / pDevIn then point at int16 pairs; the
+ * conversion is fused into the kernels' loads; overlap-save and generic backends).  Outputs stay float32. */
+uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat);
 /* expert knob: pick a tuning variant of the resolved backend's kernel (0 = default).  Also settable
  * with the environment variable IF_FIR_VARIANT read at if_fir_init. */
 uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant);

@@ -233,6 +233,27 @@ __device__ __forceinline__ cf buf_load(srd_t rsrc, unsigned voff, unsigned soff)
     const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, IF_FIR_FFT_LOAD_AUX);
     return (cf){__uint_as_float(v[0]), __uint_as_float(v[1])};
 }
+// int16 IQ front-end: one dword = (I, Q) as two int16; value = int16 * 2^-15 (exact in float32)
+__device__ __forceinline__ cf buf_load_i16(srd_t rsrc, unsigned voff, unsigned soff)
+{
+    const int w = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, IF_FIR_FFT_LOAD_AUX);
+    return (cf){(float)(short)(w & 0xffff) * 0x1p-15f, (float)(w >> 16) * 0x1p-15f};
+}
+__device__ __forceinline__ cf cvt_i16(unsigned w)
+{
+    return (cf){(float)(short)(w & 0xffffu) * 0x1p-15f, (float)((int)w >> 16) * 0x1p-15f};
+}
+// Row `row` of a block (sample row*64 + lane) whose descriptor starts at the block's first sample.  float32 rows land
+// in r[row]; int16 rows stay RAW (one dword) in rw[row] and are converted when pass 1 consumes them — converting at
+// the load would put a vmcnt wait right behind every prefetch.
+template <bool I16>
+__device__ __forceinline__ void load_row(cf (&r)[64], unsigned (&rw)[64], srd_t rsrc, int lane, int row)
+{
+    if constexpr (I16)
+        rw[row] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)lane * 4u, row * 256, IF_FIR_FFT_LOAD_AUX);
+    else
+        r[row] = buf_load(rsrc, (unsigned)lane * 8u, row * 512);
+}
 __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned soff, cf d)
 {
     u32x2_t v;
@@ -309,8 +330,8 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
     fft16<true>(c); // over k0 -> mu0
 }
 
-template <int OVL_ROWS, bool DEC4>
-__global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in, f2v *__restrict__ out,
+template <int OVL_ROWS, bool DEC4, bool I16>
+__global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
                                                         int32_t waves_total, int32_t RA, int32_t nA, int32_t RB, int32_t nB,
@@ -318,6 +339,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 {
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
+    constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
+    const char *in = reinterpret_cast<const char *>(in_);
     constexpr int L = FFT_N - OVL;         // new input samples per block
     constexpr int LOUT = DEC4 ? L / 4 : L; // outputs per block
     constexpr int EARLY_GROUPS = 3;        // dec4: batches of next-block loads issued during pass 3
@@ -384,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     unsigned int ticket = 0;
     bool ticket_pending = false;
     cf r[64];
+    unsigned rw[64]; // raw int16 pairs of the block being loaded (I16 input only)
     bool loaded = false; // the rows of `blk` are already in flight (issued by the previous iteration's epilogue)
     const unsigned voff = (unsigned)lane * 8u;
     while (blk < nblocks)
@@ -400,27 +424,32 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             if (s0 >= 0)
             {
                 // rows beyond the end of the input read 0 through the descriptor's bounds check
-                const srd_t srd = make_srd(in + s0, (N - s0) * 8);
+                const srd_t srd = make_srd(in + s0 * ISZ, (N - s0) * ISZ);
 #pragma unroll
                 for (int rho = 0; rho < 4; rho++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        r[4 * j + rho] = buf_load(srd, voff, (4 * j + rho) * 512);
+                        load_row<I16>(r, rw, srd, lane, 4 * j + rho);
             }
             else
             {
                 // first block of a call: negative stream indices come from the history (or are zero); one of the two
                 // loads of every element is out of range and returns 0
-                const srd_t srd_in = make_srd(in, N * 8);
-                const srd_t srd_h = make_srd(hist, (int64_t)(T - 1) * 8);
+                // (an int16 stream keeps its history as raw int16 pairs too, so the block stays raw: OR of the two loads)
+                const srd_t srd_in = make_srd(in, N * ISZ);
+                const srd_t srd_h = make_srd(hist, (int64_t)(T - 1) * ISZ);
 #pragma unroll
                 for (int row = 0; row < 64; row++)
                 {
                     const int64_t gidx = s0 + row * 64 + lane;
                     const int64_t hidx = gidx + (T - 1);
-                    const unsigned oi = (gidx >= 0) ? (unsigned)gidx * 8u : 0x80000000u;
-                    const unsigned oh = (gidx < 0 && hidx >= 0) ? (unsigned)hidx * 8u : 0x80000000u;
-                    r[row] = buf_load(srd_in, oi, 0) + buf_load(srd_h, oh, 0);
+                    const unsigned oi = (gidx >= 0) ? (unsigned)gidx * (unsigned)ISZ : 0x80000000u;
+                    const unsigned oh = (gidx < 0 && hidx >= 0) ? (unsigned)hidx * (unsigned)ISZ : 0x80000000u;
+                    if constexpr (I16)
+                        rw[row] = __builtin_amdgcn_raw_buffer_load_b32(srd_in, oi, 0, 0) |
+                                  __builtin_amdgcn_raw_buffer_load_b32(srd_h, oh, 0, 0);
+                    else
+                        r[row] = buf_load(srd_in, oi, 0) + buf_load(srd_h, oh, 0);
                 }
             }
         }
@@ -433,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             cf t[16];
 #pragma unroll
             for (int j = 0; j < 16; j++)
-                t[j] = r[4 * j + rho];
+                t[j] = I16 ? cvt_i16(rw[4 * j + rho]) : r[4 * j + rho];
             fft16<false>(t);
 #pragma unroll
             for (int j = 0; j < 16; j++)
@@ -480,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         }
         const int64_t s0n = blk_next * L - OVL + n0;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
-        const srd_t nsrd = make_srd(in + (next_fast ? s0n : 0), next_fast ? (N - s0n) * 8 : 0);
+        const srd_t nsrd = make_srd(in + (next_fast ? s0n : 0) * ISZ, next_fast ? (N - s0n) * ISZ : 0);
         // outputs beyond M are dropped by the descriptor's bounds check
         const int64_t obase = blk * LOUT;
         const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
@@ -509,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        r[phys(i, j)] = buf_load(nsrd, voff, phys(i, j) * 512);
+                        load_row<I16>(r, rw, nsrd, lane, phys(i, j));
                 }
                 }
             FFT_STAMP(5);
@@ -521,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        r[phys(i, j)] = buf_load(nsrd, voff, phys(i, j) * 512);
+                        load_row<I16>(r, rw, nsrd, lane, phys(i, j));
             }
             FFT_STAMP(6);
             constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
@@ -593,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        r[4 * j + rho] = buf_load(nsrd, voff, (4 * j + rho) * 512);
+                        load_row<I16>(r, rw, nsrd, lane, 4 * j + rho);
                 }
                 }
         }
@@ -604,10 +633,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     }
 }
 
-template <int OVL_ROWS, bool DEC4>
+template <int OVL_ROWS, bool DEC4, bool I16>
 static hipError_t launch_fft_t(const LaunchArgs &a)
 {
-    auto kern = fir_fft_kernel<OVL_ROWS, DEC4>;
+    auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
     constexpr int LOUT = DEC4 ? L / 4 : L;
     static bool attr_done[16] = {false};
@@ -672,9 +701,15 @@ hipError_t launch_fft(const LaunchArgs &a)
     if (!fft_supported(a.T, a.D) || !a.fft_tables)
         return hipErrorInvalidConfiguration;
     const bool small = fft_overlap_rows(a.T) == 4;
+    if (a.in_i16)
+    {
+        if (a.D == 4)
+            return small ? launch_fft_t<4, true, true>(a) : launch_fft_t<16, true, true>(a);
+        return small ? launch_fft_t<4, false, true>(a) : launch_fft_t<16, false, true>(a);
+    }
     if (a.D == 4)
-        return small ? launch_fft_t<4, true>(a) : launch_fft_t<16, true>(a);
-    return small ? launch_fft_t<4, false>(a) : launch_fft_t<16, false>(a);
+        return small ? launch_fft_t<4, true, false>(a) : launch_fft_t<16, true, false>(a);
+    return small ? launch_fft_t<4, false, false>(a) : launch_fft_t<16, false, false>(a);
 }
 
 // Host side: twiddle and H tables in the kernel's LDS image order (float64 math, rounded once to float32).

@@ -22,6 +22,7 @@ struct LaunchArgs
     const float *taps; // device, T floats
     const void *hist;  // device, T-1 samples (most recent last)
     int T, D;
+    int in_i16; // 1: input samples are interleaved int16 I,Q (value = int16 * 2^-15); FFT and generic backends only
     int ctaps;  // 1: taps are complex (interleaved re,im), FFT and generic backends only
     int64_t N;  // input samples of this call
     int32_t n0; // offset of the first output sample inside this call's input (0 ≤ n0 < D)
@@ -43,7 +44,8 @@ bool fft_supported(int T, int D);
 hipError_t launch_fft(const LaunchArgs &a);
 void fft_build_tables(const float *taps, int T, int ctaps, float *tables);
 
-hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, hipStream_t stream);
+hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, int in_i16,
+                          hipStream_t stream);
 hipError_t launch_synth(void *iq, uint64_t first, uint64_t count, uint32_t channel, const float *tone10,
                         hipStream_t stream);
 

@@ -48,13 +48,22 @@ struct Geo
     static_assert((T - 1) % 2 == 0, "odd tap counts only (pairs of samples are 16-byte aligned in LDS)");
 };
 
+// int16 IQ front-end: one dword = (I, Q) as two int16, value = int16 * 2^-15 (exact)
+__device__ __forceinline__ f2 load_i16(const f2 *__restrict__ in, int64_t g)
+{
+    const int w = reinterpret_cast<const int *>(in)[g];
+    return (f2){(float)(short)(w & 0xffff) * 0x1p-15f, (float)(w >> 16) * 0x1p-15f};
+}
+
+template <bool I16 = false>
 __device__ __forceinline__ f2 fetch_sample(const f2 *__restrict__ in, const f2 *__restrict__ hist, int T, int64_t g,
                                            int64_t N)
 {
     if (g >= 0)
-        return (g < N) ? in[g] : (f2){0.f, 0.f};
+        return (g < N) ? (I16 ? load_i16(in, g) : in[g]) : (f2){0.f, 0.f};
     const int64_t h = (int64_t)(T - 1) + g;
-    return (h >= 0) ? hist[h] : (f2){0.f, 0.f};
+    // the history of an int16 stream is kept as raw int16 pairs as well
+    return (h >= 0) ? (I16 ? load_i16(hist, h) : hist[h]) : (f2){0.f, 0.f};
 }
 
 // one input sample applied to all R accumulators.  C = sample offset relative to the lane's first output sample.
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(256) void fir_tapsplit_kernel(const f2 *__restrict_
 // (uniform index), samples straight from global/L2 (neighbouring lanes share lines).  Same summation order
 // as the fast kernels (descending k, segments of SEG).  Correctness fallback, not a performance path.
 // --------------------------------------------------------------------------------------------------------------
-template <int SEG, bool CTAPS>
+template <int SEG, bool CTAPS, bool I16>
 __global__ __launch_bounds__(256) void fir_generic_kernel(const f2 *__restrict__ in, f2 *__restrict__ out,
                                                          const float *__restrict__ taps,
                                                          const f2 *__restrict__ hist, int T, int D, int64_t N,
@@ -575,7 +584,7 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const f2 *__restrict__
     const int top = (T - 1) / SEG;
     for (int k = T - 1; k >= 0; k--)
     {
-        const f2 s = fetch_sample(in, hist, T, n - k, N);
+        const f2 s = fetch_sample<I16>(in, hist, T, n - k, N);
         const bool first = (k == T - 1) || (k % SEG == SEG - 1);
         if (first)
             acc = (f2){0.f, 0.f};
@@ -600,12 +609,23 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const f2 *__restrict__
 // --------------------------------------------------------------------------------------------------------------
 // history update: hist_out = last T-1 samples of (hist_in ‖ in)
 // --------------------------------------------------------------------------------------------------------------
+template <bool I16>
 __global__ void fir_history_kernel(const f2 *__restrict__ in, const f2 *__restrict__ hist_in, f2 *__restrict__ hist_out,
                                    int T, int64_t N)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < T - 1)
-        hist_out[i] = fetch_sample(in, hist_in, T, N - (int64_t)(T - 1) + i, N);
+    if (i >= T - 1)
+        return;
+    const int64_t g = N - (int64_t)(T - 1) + i;
+    if constexpr (I16)
+    {
+        // raw copy of the int16 pairs (4 bytes per sample)
+        const int *src = reinterpret_cast<const int *>(in), *hsrc = reinterpret_cast<const int *>(hist_in);
+        const int64_t h = (int64_t)(T - 1) + g;
+        reinterpret_cast<int *>(hist_out)[i] = (g >= 0) ? src[g] : (h >= 0 ? hsrc[h] : 0);
+    }
+    else
+        hist_out[i] = fetch_sample<false>(in, hist_in, T, g, N);
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -823,14 +843,19 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
         const int64_t blocks = (a.M + 255) / 256;
         if (blocks > 0x7fffffffLL)
             return hipErrorInvalidValue;
-        if (a.ctaps)
-            hipLaunchKernelGGL((fir_generic_kernel<32, true>), dim3((unsigned)blocks), dim3(256), 0, a.stream,
-                               reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,
-                               reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M);
+#define IF_FIR_GENERIC_LAUNCH(CT_, I16_)                                                                          \
+    hipLaunchKernelGGL((fir_generic_kernel<32, CT_, I16_>), dim3((unsigned)blocks), dim3(256), 0, a.stream,        \
+                       reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,                  \
+                       reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M)
+        if (a.ctaps && a.in_i16)
+            IF_FIR_GENERIC_LAUNCH(true, true);
+        else if (a.ctaps)
+            IF_FIR_GENERIC_LAUNCH(true, false);
+        else if (a.in_i16)
+            IF_FIR_GENERIC_LAUNCH(false, true);
         else
-            hipLaunchKernelGGL((fir_generic_kernel<32, false>), dim3((unsigned)blocks), dim3(256), 0, a.stream,
-                               reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,
-                               reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M);
+            IF_FIR_GENERIC_LAUNCH(false, false);
+#undef IF_FIR_GENERIC_LAUNCH
         return hipGetLastError();
     }
     return hipErrorInvalidConfiguration;
@@ -841,13 +866,20 @@ bool direct_supported(int T, int D)
     return (T == 255 || T == 127) && (D == 1 || D == 4);
 }
 
-hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, hipStream_t stream)
+hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, int in_i16,
+                          hipStream_t stream)
 {
     if (T <= 1)
         return hipSuccess;
     const int blocks = (T - 1 + 255) / 256;
-    hipLaunchKernelGGL(fir_history_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const f2 *>(in),
-                       reinterpret_cast<const f2 *>(hist_in), reinterpret_cast<f2 *>(hist_out), T, N);
+    if (in_i16)
+        hipLaunchKernelGGL(fir_history_kernel<true>, dim3(blocks), dim3(256), 0, stream,
+                           reinterpret_cast<const f2 *>(in), reinterpret_cast<const f2 *>(hist_in),
+                           reinterpret_cast<f2 *>(hist_out), T, N);
+    else
+        hipLaunchKernelGGL(fir_history_kernel<false>, dim3(blocks), dim3(256), 0, stream,
+                           reinterpret_cast<const f2 *>(in), reinterpret_cast<const f2 *>(hist_in),
+                           reinterpret_cast<f2 *>(hist_out), T, N);
     return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@ struct if_fir_ctx
     hipStream_t stream;
     int T, D;
     int ctaps; // taps are complex (interleaved re,im)
+    int in_i16; // input format: 0 = float32 I,Q; 1 = int16 I,Q
     uint32_t backend_req;
     uint32_t backend;
     int variant;
@@ -72,17 +73,17 @@ static uint32_t resolve_backend(const if_fir_ctx *ctx, uint32_t req)
 {
     if (req != IF_FIR_BACKEND_AUTO)
         return req;
-    if (if_fir::fft_supported(ctx->T, ctx->D) && (ctx->T >= 32 || ctx->ctaps))
+    if (if_fir::fft_supported(ctx->T, ctx->D) && (ctx->T >= 32 || ctx->ctaps || ctx->in_i16))
         return IF_FIR_BACKEND_HIP_FFT;
-    if (ctx->ctaps)
+    if (ctx->ctaps || ctx->in_i16)
         return IF_FIR_BACKEND_HIP_GENERIC;
     return if_fir::direct_supported(ctx->T, ctx->D) ? IF_FIR_BACKEND_HIP_DIRECT : IF_FIR_BACKEND_HIP_TAPSPLIT;
 }
 
 static bool backend_ok(const if_fir_ctx *ctx, uint32_t b)
 {
-    if (ctx->ctaps && b != IF_FIR_BACKEND_HIP_FFT && b != IF_FIR_BACKEND_HIP_GENERIC)
-        return false; // complex taps: overlap-save and generic kernels only
+    if ((ctx->ctaps || ctx->in_i16) && b != IF_FIR_BACKEND_HIP_FFT && b != IF_FIR_BACKEND_HIP_GENERIC)
+        return false; // complex taps / int16 input: overlap-save and generic kernels only
     switch (b)
     {
     case IF_FIR_BACKEND_HIP_DIRECT:
@@ -388,6 +389,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.T = ctx->T;
     a.D = ctx->D;
     a.ctaps = ctx->ctaps;
+    a.in_i16 = ctx->in_i16;
     a.N = (int64_t)n;
     a.n0 = (int32_t)n0;
     a.M = (int64_t)m;
@@ -403,7 +405,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     else
         HIP_TRY(ctx, if_fir::launch_fir(a, ctx->variant));
     HIP_TRY(ctx, if_fir::launch_history(in, ctx->d_hist[ctx->hist_cur], ctx->d_hist[ctx->hist_cur ^ 1], ctx->T,
-                                        (int64_t)n, ctx->stream));
+                                        (int64_t)n, ctx->in_i16, ctx->stream));
     if (commit)
     {
         ctx->hist_cur ^= 1;
@@ -454,7 +456,8 @@ IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float
         HIP_TRY(pCtx, hipMalloc(&pCtx->d_stage_in, 8 * pCtx->max_samples));
         HIP_TRY(pCtx, hipMalloc(&pCtx->d_stage_out, 8 * (pCtx->max_samples / pCtx->D + 1)));
     }
-    HIP_TRY(pCtx, hipMemcpyAsync(pCtx->d_stage_in, pfIQIn, 8 * ullSamples, hipMemcpyHostToDevice, pCtx->stream));
+    HIP_TRY(pCtx, hipMemcpyAsync(pCtx->d_stage_in, pfIQIn, (pCtx->in_i16 ? 4 : 8) * ullSamples, hipMemcpyHostToDevice,
+                                 pCtx->stream));
     uint64_t m = 0;
     if (!run_device(pCtx, pCtx->d_stage_in, pCtx->d_stage_out, ullSamples, &m, true))
         return 0;
@@ -595,4 +598,37 @@ IF_FIR_API uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, u
     if (hipMemcpy(pullOut, pCtx->d_dbg, sizeof(uint64_t) * n, hipMemcpyDeviceToHost) != hipSuccess)
         return 0;
     return n;
+}
+
+// Input sample format: IF_FIR_INPUT_F32 (default) or IF_FIR_INPUT_I16 = interleaved int16 I,Q with
+// value = int16 * 2^-15, converted inside the kernels' loads (overlap-save and generic backends).  Must be chosen
+// before the first sample is processed (or right after if_fir_reset): the history buffer holds samples in the
+// input format.
+IF_FIR_API uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat)
+{
+    if (!pCtx)
+        return 0;
+    if (ulFormat > IF_FIR_INPUT_I16)
+    {
+        set_err(pCtx, "if_fir_set_input_format: unknown format %u", ulFormat);
+        return 0;
+    }
+    const int old = pCtx->in_i16;
+    pCtx->in_i16 = (ulFormat == IF_FIR_INPUT_I16);
+    const uint32_t b = resolve_backend(pCtx, pCtx->backend_req);
+    if (!backend_ok(pCtx, b))
+    {
+        pCtx->in_i16 = old;
+        set_err(pCtx, "if_fir_set_input_format: backend %u does not take this input format", pCtx->backend_req);
+        return 0;
+    }
+    if (b == IF_FIR_BACKEND_HIP_FFT && !ensure_fft_tables(pCtx))
+    {
+        pCtx->in_i16 = old;
+        return 0;
+    }
+    pCtx->backend = b;
+    if (old != pCtx->in_i16)
+        return if_fir_reset(pCtx); // the history buffer holds samples in the input format: start a fresh stream
+    return 1;
 }

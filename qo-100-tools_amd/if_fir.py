@@ -8,13 +8,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libif_fir.so")
 
+INPUT_F32, INPUT_I16 = 0, 1
 BACKEND_AUTO, BACKEND_HIP_DIRECT, BACKEND_HIP_TAPSPLIT, BACKEND_HIP_GENERIC, BACKEND_HIP_FFT = range(5)
 WINDOW_RECT, WINDOW_HAMMING, WINDOW_HANN, WINDOW_BLACKMAN = range(4)
 
 # every symbol include/if_fir.h declares (tests check the library exports all of them)
 EXPORTS = [
     "if_bpf_design", "if_bpf_design_complex", "if_fir_init", "if_fir_init_complex", "if_fir_destroy", "if_fir_reset", "if_fir_set_backend", "if_fir_get_backend",
-    "if_fir_set_tuning", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
+    "if_fir_set_tuning", "if_fir_set_input_format", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
 ]
@@ -54,6 +55,8 @@ def lib():
     L.if_fir_set_backend.restype = u8
     L.if_fir_get_backend.argtypes = [vp]
     L.if_fir_get_backend.restype = u32
+    L.if_fir_set_input_format.argtypes = [vp, u32]
+    L.if_fir_set_input_format.restype = u8
     L.if_fir_set_tuning.argtypes = [vp, u32]
     L.if_fir_set_tuning.restype = u8
     L.if_fir_set_stream.argtypes = [vp, vp]
@@ -162,6 +165,10 @@ class IfFir:
     def get_backend(self):
         return int(lib().if_fir_get_backend(self._ctx))
 
+    def set_input_format(self, fmt):
+        self._check(lib().if_fir_set_input_format(self._ctx, int(fmt)))
+        self._i16 = (int(fmt) == INPUT_I16)
+
     def set_tuning(self, variant):
         self._check(lib().if_fir_set_tuning(self._ctx, int(variant)))
 
@@ -182,15 +189,19 @@ class IfFir:
     def process(self, iq):
         """if_fir_process(): host interleaved float32 (or complex64) in, interleaved float32 out."""
         iq = np.asarray(iq)
-        if np.iscomplexobj(iq):
-            iq = np.ascontiguousarray(iq.astype(np.complex64)).view(np.float32)
-        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        if getattr(self, "_i16", False):
+            iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1)
+        else:
+            if np.iscomplexobj(iq):
+                iq = np.ascontiguousarray(iq.astype(np.complex64)).view(np.float32)
+            iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
         n = iq.size // 2
         out = np.empty(2 * self.out_count(n), dtype=np.float32)
         m = ctypes.c_uint64(0)
         dummy = np.zeros(2, dtype=np.float32)
-        self._check(lib().if_fir_process(self._ctx, _f32p(iq if n else dummy), _f32p(out if out.size else dummy), n,
-                                         ctypes.byref(m)))
+        src = iq if n else dummy
+        self._check(lib().if_fir_process(self._ctx, ctypes.cast(src.ctypes.data, ctypes.POINTER(ctypes.c_float)),
+                                         _f32p(out if out.size else dummy), n, ctypes.byref(m)))
         assert m.value * 2 == out.size
         return out
 

@@ -362,3 +362,37 @@ def test_complex_taps_golden(fir, oracle):
         with fir.IfFir(gold["ctaps_255"], d, 4096, complex_taps=True) as f:
             l2, mx = oracle.err_metrics(f.process(gold["x"]), gold["yc_T255_D%d" % d])
         assert l2 <= TOL and mx <= TOL
+
+
+@pytest.mark.parametrize("t,d", [(255, 4), (255, 1), (1023, 1), (127, 4), (31, 3)])
+def test_int16_input_front_end(fir, oracle, t, d):
+    """int16 IQ input: value = int16 * 2^-15 converted inside the kernels' loads.  Overlap-save backend
+    within SPEC tolerance, generic kernel bit-exact, ragged streaming, and the real-only backends refuse the format."""
+    rng = np.random.default_rng(900 + t + d)
+    taps = fir.bpf_design(t)
+    n = 50_007
+    xi = np.clip(np.round(oracle.synth_iq(n, 13) * 16384.0), -32768, 32767).astype(np.int16)
+    xi[: 2 * 100] = rng.integers(-32768, 32768, 2 * 100).astype(np.int16)       # full-scale corner values
+    xf = xi.astype(np.float32) * np.float32(2.0 ** -15)
+    ref = oracle.fir_f64(taps, xf, d)
+    with fir.IfFir(taps, d, n) as f:
+        f.set_input_format(fir.INPUT_I16)
+        assert f.get_backend() == (fir.BACKEND_HIP_FFT if d in (1, 4) else fir.BACKEND_HIP_GENERIC)
+        y = f.process(xi)
+        l2, mx = oracle.err_metrics(y, ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        f.reset()
+        cuts = [0, 1, 255, 3841, 20_000, n]
+        parts = [f.process(xi[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
+        assert l2 <= TOL and mx <= TOL
+        f.set_backend(fir.BACKEND_HIP_GENERIC)
+        f.reset()
+        assert np.array_equal(f.process(xi), oracle.fir_f32fma(taps, xf, d, seg_mode=1, seg_len=32))
+        for b in (fir.BACKEND_HIP_DIRECT, fir.BACKEND_HIP_TAPSPLIT):
+            with pytest.raises(fir.IfFirError):
+                f.set_backend(b)
+    with fir.IfFir(taps, d, n, backend=fir.BACKEND_HIP_TAPSPLIT) as f:
+        with pytest.raises(fir.IfFirError):
+            f.set_input_format(fir.INPUT_I16)        # forced real-only backend: format refused, context usable
+        assert f.process(xf).size == 2 * oracle.out_count(0, n, d)
