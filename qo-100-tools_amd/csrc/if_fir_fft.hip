@@ -262,26 +262,16 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
     __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, IF_FIR_FFT_STORE_AUX);
 }
 
-// one returning atomic add issued by lane 0 only, WITHOUT the wait hipcc would put right behind it (that wait is a
-// vmcnt(0): it would drain the prefetched rows of the next block); the caller waits with queue_ticket_wait() where
-// nothing younger is in flight
-__device__ __forceinline__ unsigned queue_ticket_issue(unsigned int *queue)
+// next run of this wave: one returning atomic add by lane 0, waited for on the spot.  It is taken at the last block of
+// a run, before that block's pass 3 issues the next rows, so hipcc's vmcnt(0) behind it drains nothing but the atomic.
+// (An earlier version issued the atomic a run ahead through inline asm and waited later: the compiler cannot know
+// that the destination VGPR is still in flight and may spill or copy it before the value lands -- it did, once a
+// change made the kernel spill: every wave then stopped after its first run.  Do not bring that back.)
+__device__ __forceinline__ unsigned queue_ticket(unsigned int *queue, int lane)
 {
-    unsigned t;
-    unsigned long long save;
-    const unsigned one = 1u;
-    asm volatile("s_mov_b64 %1, exec\n\t"
-                 "s_mov_b64 exec, 1\n\t"
-                 "global_atomic_add %0, %2, %3, off sc0\n\t"
-                 "s_mov_b64 exec, %1"
-                 : "=&v"(t), "=&s"(save)
-                 : "v"(queue), "v"(one)
-                 : "memory");
-    return t;
-}
-__device__ __forceinline__ unsigned queue_ticket_wait(unsigned t)
-{
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)::"memory");
+    unsigned t = 0;
+    if (lane == 0)
+        t = atomicAdd(queue, 1u);
     return __builtin_amdgcn_readfirstlane(t);
 }
 
@@ -379,8 +369,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #else
 #define FFT_STAMP(slot) (void)0
 #endif
-    // Work distribution: wave w starts with ticket w; further tickets come from one atomic counter, reserved a whole
-    // run ahead.  (One ticket per BLOCK saturates the counter: a single address takes
+    // Work distribution: wave w starts with ticket w; further tickets come from one atomic counter, one per RUN of
+    // blocks (queue_ticket() at the last block of a run).  (One ticket per BLOCK saturates the counter: a single address takes
     // ~88 atomics/us, 70k blocks would cost 0.8 ms by themselves.)
     // guided schedule: tickets [0, nA) are runs of RA blocks, the next nB tickets runs of RB blocks, the rest single
     // blocks, so that the tail of the launch is handed out in small pieces and all waves finish together
@@ -404,8 +394,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     };
     int64_t blk, blk_end;
     run_range((int64_t)blockIdx.x * FFT_WAVES + wid, blk, blk_end);
-    unsigned int ticket = 0;
-    bool ticket_pending = false;
     cf r[64];
     unsigned rw[64]; // raw int16 pairs of the block being loaded (I16 input only)
     bool loaded = false; // the rows of `blk` are already in flight (issued by the previous iteration's epilogue)
@@ -413,11 +401,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     while (blk < nblocks)
     {
         FFT_STAMP(0);
-        if (!ticket_pending)
-        {
-            ticket = queue_ticket_issue(queue); // next run for this wave, resolved at the last block of this run
-            ticket_pending = true;
-        }
         const int64_t s0 = blk * L - OVL + n0; // stream index of the block's first sample (n0: decimation phase)
         if (!loaded && !(diag & 1))
         {
@@ -504,8 +487,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         int64_t blk_next = blk + 1;
         if (blk_next >= blk_end)
         {
-            run_range((int64_t)waves_total + (int64_t)queue_ticket_wait(ticket), blk_next, blk_end);
-            ticket_pending = false;
+            run_range((int64_t)waves_total + (int64_t)queue_ticket(queue, lane), blk_next, blk_end);
         }
         const int64_t s0n = blk_next * L - OVL + n0;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
@@ -660,7 +642,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
         return hipSuccess;
     // guided schedule (see the kernel): ~80 % of the blocks in runs of RA, ~15 % in runs of RB, the rest singly.  Runs
     // keep the counter far from saturation (~88 tickets/us); small pieces at the end keep the tail short.
-    const int64_t waves_max = (int64_t)cus[dev] * FFT_WAVES;
+    const int64_t wgs_max = (a.grid_limit > 0 && a.grid_limit < cus[dev]) ? a.grid_limit : cus[dev];
+    const int64_t waves_max = wgs_max * FFT_WAVES;
     int64_t RA = nblocks / (waves_max * 4);
     RA = RA < 1 ? 1 : (RA > 8 ? 8 : RA);
     int64_t RB = RA >= 4 ? 2 : 1;
@@ -671,7 +654,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     if (nA * RA + nB * RB > nblocks)
         nB = (nblocks - nA * RA) / RB;
     const int64_t tickets = nA + nB + (nblocks - nA * RA - nB * RB);
-    int64_t wgs = cus[dev];
+    int64_t wgs = wgs_max;
     if (wgs * FFT_WAVES > tickets)
         wgs = (tickets + FFT_WAVES - 1) / FFT_WAVES;
     hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);

@@ -33,6 +33,7 @@ struct LaunchArgs
     const void *fft_tables; // device, FFT_TABLE_FLOATS floats (overlap-save backend) or nullptr
     void *queue; // device, 16 bytes: atomic run queue of the persistent kernel (zeroed by the launcher)
     int diag;  // development diagnostics for the FFT kernel (0 in production)
+    int grid_limit; // FFT backend: at most this many workgroups (0 = one per CU); same results, used by the queue tests
     void *dbg; // optional diagnostic stamp buffer (8192 x 4 x u64) or nullptr
 };
 

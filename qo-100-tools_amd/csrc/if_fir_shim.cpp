@@ -381,7 +381,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
         *pout = m;
     if (n == 0)
         return 1;
-    if_fir::LaunchArgs a;
+    if_fir::LaunchArgs a{};
     a.in = in;
     a.out = out;
     a.taps = ctx->d_taps;
@@ -399,7 +399,11 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.fft_tables = ctx->d_fft_tables;
     a.queue = ctx->d_queue;
     a.dbg = ctx->d_dbg;
-    a.diag = (ctx->backend == IF_FIR_BACKEND_HIP_FFT && ctx->variant >= 1000) ? ctx->variant - 1000 : 0;
+    // FFT tuning variants: 1000 + bits = development diagnostics (wrong results), 2000 + k = launch at most k workgroups
+    // (same results; lets small inputs go through the run queue, tests/test_gpu_parity.py)
+    const bool fft_var = ctx->backend == IF_FIR_BACKEND_HIP_FFT;
+    a.diag = (fft_var && ctx->variant >= 1000 && ctx->variant < 2000) ? ctx->variant - 1000 : 0;
+    a.grid_limit = (fft_var && ctx->variant > 2000 && ctx->variant < 3000) ? ctx->variant - 2000 : 0;
     if (ctx->backend == IF_FIR_BACKEND_HIP_FFT)
         HIP_TRY(ctx, if_fir::launch_fft(a));
     else

@@ -88,6 +88,18 @@ def test_full_size_fft_backend(fir, oracle, gpu_ok, t, d, log2n):
             got = y[2 * first_out:2 * first_out + ref.size].cpu().numpy()
             l2, mx = oracle.err_metrics(got, ref)
             assert l2 <= 1e-6 and mx <= 1e-6, (start, l2, mx)
+        # completeness: EVERY output of the launch against the direct form (or the one-output-per-thread kernel) on the
+        # same input -- windows alone can miss blocks a work-queue bug leaves unwritten
+        f.reset()
+        f.set_backend(fir.BACKEND_HIP_DIRECT if (t, d) in ((255, 4), (127, 1)) else fir.BACKEND_HIP_GENERIC)
+        yd = torch.empty_like(y)
+        assert f.process_device(x.data_ptr(), yd.data_ptr(), n) == m
+        f.synchronize()
+        scale = yd.abs().max().item()
+        assert scale > 0.1
+        assert (y - yd).abs().max().item() <= 2e-6 * scale   # each side is within 1e-6 of the float64 result
+        del yd
+        f.set_backend(fir.BACKEND_HIP_FFT)
         f.reset()
         cut = (n // 2) + 12345
         y2 = torch.empty_like(y)

@@ -257,6 +257,41 @@ def test_fft_backend_block_edges(fir, oracle, n):
         assert np.max(np.abs(y - ref)) <= 1e-6 * max(scale, 0.5), (t, n, np.max(np.abs(y - ref)))
 
 
+@pytest.mark.parametrize("t,d,i16", [(255, 4, False), (255, 1, False), (1023, 4, False), (255, 4, True)])
+def test_fft_backend_run_queue_on_small_grid(fir, oracle, t, d, i16):
+    """The overlap-save kernel hands out runs of blocks through an atomic queue, which a normal-size test input never
+    reaches (256 CUs x 8 waves each take one run and are done).  Tuning 2000+k launches at most k workgroups: ~270
+    blocks on 8 or 24 waves go through every stage of the guided schedule (runs of RA, runs of RB, single blocks).
+    Which wave computes a block must not matter: bit-identical to the default launch, and within SPEC tolerance."""
+    n = 1_050_007
+    taps = fir.bpf_design(t)
+    if i16:
+        xi = np.random.default_rng(77).integers(-32768, 32768, 2 * n, dtype=np.int16)
+        x = xi.astype(np.float32) * np.float32(2.0 ** -15)
+    else:
+        x = oracle.synth_iq(n, 21)
+    ref = oracle.fir_f64(taps, x, d)
+    with fir.IfFir(taps, d, n) as f:
+        if i16:
+            f.set_input_format(fir.INPUT_I16)
+        f.set_backend(fir.BACKEND_HIP_FFT)
+        src = xi if i16 else x
+        y0 = f.process(src)
+        l2, mx = oracle.err_metrics(y0, ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        for k in (1, 3):
+            f.reset()
+            f.set_tuning(2000 + k)
+            yk = f.process(src)
+            assert np.array_equal(yk, y0), (k, int(np.argmax(yk != y0)))
+        # streaming through the limited grid as well: the first block of a call takes the history path
+        f.reset()
+        cuts = [0, 333_333, 700_001, n]
+        parts = [f.process(src[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+
+
 def test_fft_backend_rejects_unsupported(fir):
     with fir.IfFir(fir.bpf_design(255), 3, 1000) as f:
         with pytest.raises(fir.IfFirError):
