@@ -18,6 +18,8 @@
 
 #include <cmath>
 
+#include <vector>
+
 #include "if_fir_kernels.h"
 
 namespace if_fir
@@ -55,6 +57,14 @@ __device__ __forceinline__ cf cmul_s(cf a, cf w) // w wave-uniform (compile-time
         asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
     else
         asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+    return d;
+}
+// acc + a * w in two packed FMAs (w in a VGPR pair)
+__device__ __forceinline__ cf cmac_v(cf acc, cf a, cf w)
+{
+    cf t, d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
     return d;
 }
 // a + w*b and a - w*b with w = -j (forward) or +j (inverse): one v_pk_add_f32 each
@@ -364,7 +374,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     do                                                                                                           \
     {                                                                                                            \
         if (dbg_on && dbg_it < 32 && lane == 0)                                                                  \
+        {                                                                                                        \
             dbg[(((blockIdx.x >> 6) * 2 + wid) * 32 + dbg_it) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+            dbg[4096 + (((blockIdx.x >> 6) * 2 + wid) * 32 + dbg_it) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                                        \
     } while (0)
 #else
 #define FFT_STAMP(slot) (void)0
@@ -491,7 +504,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         }
         const int64_t s0n = blk_next * L - OVL + n0;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
-        const srd_t nsrd = make_srd(in + (next_fast ? s0n : 0) * ISZ, next_fast ? (N - s0n) * ISZ : 0);
+        // diag 16: every wave fetches the same (cached) block -> separates HBM effects from the instruction stream's
+        const int64_t s0f = (diag & 16) ? (int64_t)(lane & 0) : s0n;
+        const srd_t nsrd = make_srd(in + (next_fast ? s0f : 0) * ISZ, next_fast ? (N - s0f) * ISZ : 0);
         // outputs beyond M are dropped by the descriptor's bounds check
         const int64_t obase = blk * LOUT;
         const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
@@ -506,13 +521,24 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     t[j] = r[phys(i, j)];
-                fft16<false>(t);
+                // Only the first radix-4 stage of the 16-point transform is computed: y[q][m0] = sum_m1 t[m0 + 4 m1] W4^(m1 q).
+                // Its second stage, the multiplication by H and the alias fold are one linear map per output,
+                //   z(i, q) = sum_p H(q + 4p) Y(q + 4p) = sum_m0 y[q][m0] * G[m0][q],
+                //   G[m0][q] = W16^(m0 q) * sum_p H(q + 4p) W4^(m0 p)      (host table, fft_build_tables)
+                // i.e. 16 complex MACs instead of 4 butterflies + 8 twiddles + 16 multiplies + 12 adds.
+                cf y[4][4];
 #pragma unroll
-                for (int j = 0; j < 16; j++)
-                    t[j] = cmul_v<false>(t[j], hp[(i * 16 + j) * 64 + lane]);
+                for (int m0 = 0; m0 < 4; m0++)
+                    bfly4<false>(t[m0], t[m0 + 4], t[m0 + 8], t[m0 + 12], y[0][m0], y[1][m0], y[2][m0], y[3][m0]);
 #pragma unroll
-                for (int k2p = 0; k2p < 4; k2p++)
-                    z[4 * i + k2p] = (t[k2p] + t[k2p + 4]) + (t[k2p + 8] + t[k2p + 12]);
+                for (int q = 0; q < 4; q++)
+                {
+                    cf acc = cmul_v<false>(y[q][0], hp[(i * 16 + q) * 64 + lane]);
+#pragma unroll
+                    for (int m0 = 1; m0 < 4; m0++)
+                        acc = cmac_v(acc, y[q][m0], hp[(i * 16 + m0 * 4 + q) * 64 + lane]);
+                    z[4 * i + q] = acc;
+                }
                 // the 16 registers of this group are dead: refill them with rows of the next block right away, so the
                 // loads have the rest of pass 3 and the whole small inverse to land (EARLY_GROUPS of the 4 batches;
                 // the last ones are issued after the inverse to keep its temporaries out of scratch)
@@ -526,6 +552,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             FFT_STAMP(5);
             cf c[16];
             inverse_dec4(z, c, twd, twe, xb, lane);
+            FFT_STAMP(6);
             if (next_fast)
             {
 #pragma unroll
@@ -534,7 +561,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int j = 0; j < 16; j++)
                         load_row<I16>(r, rw, nsrd, lane, phys(i, j));
             }
-            FFT_STAMP(6);
             constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
 #pragma unroll
             for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
@@ -700,7 +726,7 @@ hipError_t launch_fft(const LaunchArgs &a)
 //   [32 KB, 64 KB)  hp [(i*16+k2)*64 + lane]   = FFT(taps)[(4*(lane/16)+i) + 16*(lane%16) + 256*k2] / 4096
 //   [64 KB, 66 KB)  tw2[k1*16 + n2]            = W256^(n2*k1)
 //   [66 KB, 82 KB)  twd, twe: twiddles of the decimate-by-4 1024-point inverse
-void fft_build_tables(const float *taps, int T, int ctaps, float *tables /* FFT_TABLE_FLOATS floats */)
+void fft_build_tables(const float *taps, int T, int ctaps, int D, float *tables /* FFT_TABLE_FLOATS floats */)
 {
     const double PI2 = 6.283185307179586476925286766559;
     float *tw1 = tables, *hp = tables + 2 * 4096, *tw2 = tables + 4 * 4096;
@@ -741,7 +767,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, float *tables /* FFT_
             tw2[2 * (k1 * 16 + n2) + 1] = (float)sin(a);
         }
     // DFT of the taps in float64 with an exact-argument table
-    static double ct[4096], st[4096];
+    std::vector<double> ct(4096), st(4096), hd(2 * 4096); // not static: contexts may be created from several threads
     for (int e = 0; e < 4096; e++)
     {
         ct[e] = cos(-PI2 * (double)e / 4096.0);
@@ -761,9 +787,33 @@ void fft_build_tables(const float *taps, int T, int ctaps, float *tables /* FFT_
                     re += hr * ct[e] - hi * st[e];
                     im += hr * st[e] + hi * ct[e];
                 }
-                hp[2 * ((i * 16 + k2) * 64 + lane) + 0] = (float)(re / 4096.0);
-                hp[2 * ((i * 16 + k2) * 64 + lane) + 1] = (float)(im / 4096.0);
+                hd[2 * ((i * 16 + k2) * 64 + lane) + 0] = re / 4096.0;
+                hd[2 * ((i * 16 + k2) * 64 + lane) + 1] = im / 4096.0;
             }
+    if (D != 4)
+    {
+        for (int e = 0; e < 2 * 4096; e++)
+            hp[e] = (float)hd[e];
+        return;
+    }
+    // decimate-by-4 kernels: the table holds G[m0][q] = W16^(m0 q) * sum_p H(q + 4p) W4^(m0 p) at ((i*16 + 4*m0 + q)*64 + lane)
+    // (second radix-4 stage of pass 3, multiplication by H and alias fold merged; see the kernel)
+    for (int i = 0; i < 4; i++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int m0 = 0; m0 < 4; m0++)
+                for (int q = 0; q < 4; q++)
+                {
+                    double re = 0.0, im = 0.0;
+                    for (int p = 0; p < 4; p++)
+                    {
+                        const double *h = &hd[2 * ((i * 16 + q + 4 * p) * 64 + lane)];
+                        const int e = (256 * m0 * q + 1024 * m0 * p) & 4095; // W16^(m0 q) W4^(m0 p) as a power of W4096
+                        re += h[0] * ct[e] - h[1] * st[e];
+                        im += h[0] * st[e] + h[1] * ct[e];
+                    }
+                    hp[2 * ((i * 16 + 4 * m0 + q) * 64 + lane) + 0] = (float)re;
+                    hp[2 * ((i * 16 + 4 * m0 + q) * 64 + lane) + 1] = (float)im;
+                }
 }
 
 } // namespace if_fir

@@ -43,7 +43,7 @@ hipError_t launch_fir(const LaunchArgs &a, int variant);
 constexpr int FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024);
 bool fft_supported(int T, int D);
 hipError_t launch_fft(const LaunchArgs &a);
-void fft_build_tables(const float *taps, int T, int ctaps, float *tables);
+void fft_build_tables(const float *taps, int T, int ctaps, int D, float *tables);
 
 hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, int in_i16,
                           hipStream_t stream);

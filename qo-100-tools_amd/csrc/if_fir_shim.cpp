@@ -109,7 +109,7 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
         set_err(ctx, "overlap-save tables: out of host memory");
         return 0;
     }
-    if_fir::fft_build_tables(ctx->h_taps, ctx->T, ctx->ctaps, tab);
+    if_fir::fft_build_tables(ctx->h_taps, ctx->T, ctx->ctaps, ctx->D, tab);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * if_fir::FFT_TABLE_FLOATS);

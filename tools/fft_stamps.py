@@ -12,6 +12,7 @@ import __graft_entry__ as g  # noqa: E402
 import bench  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "fir255_dec4_2p28"
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # 1001/1002/1003: skip loads / stores / both
 taps_n, decim, log2n, _ = bench.WORKLOADS[wl]
 n = 1 << log2n
 fir = g.load_pkg().if_fir
@@ -19,6 +20,7 @@ torch.cuda.set_device(0)
 x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
 with fir.IfFir(fir.bpf_design(taps_n), decim, 0) as f:
     f.set_backend(fir.BACKEND_HIP_FFT)
+    f.set_tuning(variant)
     y = torch.empty(2 * f.out_count(n), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     f.synth_device(x.data_ptr(), 0, n, 0)
@@ -27,9 +29,17 @@ with fir.IfFir(fir.bpf_design(taps_n), decim, 0) as f:
     for _ in range(3):
         f.process_device(x.data_ptr(), y.data_ptr(), n)
     f.synchronize()
-    s = f.debug_stamps(2048).astype(np.int64).reshape(-1)[:8 * 32 * 8].reshape(8, 32, 8)
+    raw = f.debug_stamps(2048).astype(np.int64).reshape(-1)
+    s = raw[:8 * 32 * 8].reshape(8, 32, 8)
+    c = raw[4096:4096 + 8 * 32 * 8].reshape(8, 32, 8)   # s_memtime (shader clock) beside s_memrealtime (100 MHz)
+    for w in range(2):
+        ok = s[w][:, 7] > 0
+        if ok.sum() > 4:
+            i0, i1 = np.flatnonzero(ok)[1], np.flatnonzero(ok)[-1]
+            print("wave %d shader clock over iterations %d..%d: %.3f GHz" %
+                  (w, i0, i1, (c[w][i1, 7] - c[w][i0, 0]) / ((s[w][i1, 7] - s[w][i0, 0]) * 10.0)))
     names = ["top->loaded", "pass1", "exch1+pass2", "exch2", "pass3(+fold,issue)", "inverse", "stores"]
-    print(wl)
+    print(wl, 'variant', variant)
     for w in range(4):
         d = np.diff(s[w], axis=1) * 0.01   # us
         tot = (s[w][:, 7] - s[w][:, 0]) * 0.01
