@@ -113,8 +113,16 @@ def cpu_baseline(taps_arr, decim, budget_s=10.0):
         times.append(time.perf_counter() - t0)
         spent += times[-1]
     kernel_dt, reps = min(times), len(times)
+    n1 = 1 << 22                                             # single-thread figure on a shorter sample (~1 s)
+    args1 = (taps_arr.ctypes.data_as(f32p), t, decim, buf.ctypes.data_as(f32p), n1, y.ctypes.data_as(f32p), 1)
+    t1 = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        lib.oracle_fir_c64_f32_omp(*args1)
+        t1.append(time.perf_counter() - t0)
     return {"value": round(n / kernel_dt / 1e6, 2), "unit": "MSamples/s", "cores": threads, "kind": "port",
             "median": round(n / float(np.median(times)) / 1e6, 2), "cpu_seconds": round(spent, 1),
+            "single_thread": round(n1 / min(t1) / 1e6, 2),
             "sample": "2^26 IQ samples of the same synthetic stream, taps=%d decimation=%d, float32 OpenMP direct form "
                       "(oracle/if_fir_oracle.c oracle_fir_c64_f32_omp), best of %d runs, %s build; build-authored CPU "
                       "baseline: the reference has no CPU implementation" %
@@ -206,8 +214,11 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
+    step_ev = []
     for _ in range(args.steps):
         step_stream()
+        step_ev.append(torch.cuda.Event(enable_timing=True))
+        step_ev[-1].record(stream)
     ev1.record(stream)
     torch.cuda.synchronize()
     if use_dist:
@@ -215,6 +226,7 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+    per_step = [a.elapsed_time(b) for a, b in zip([ev0] + step_ev[:-1], step_ev)]   # this rank's steps, HIP events
     t = torch.tensor([wall, dev_ms_per_step], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -344,6 +356,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(dev_ms_max, 4),
+                         "kernel_ms_median": round(float(np.median(per_step)), 4),
+                         "kernel_ms_min": round(float(np.min(per_step)), 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "HIP events on the launch stream around the timed steps / steps (includes the "
                                  "history-update kernel and the queue memset)"},

@@ -133,6 +133,36 @@ uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulW
 /* "gfx950", CU count, etc.: writes a short description of the context's device */
 uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOutBytes);
 
+/* ---- multi-channel front (BUILD-DEFINED, the reference has no filter surface) -------------------
+ * One process per GPU.  Channel c is filtered by rank if_fir_mc_owner(c, world) = c mod world with its own taps and
+ * its own streaming state.  The channel inputs and outputs live on rank 0's GPU; if_fir_mc_process_device() is called
+ * by EVERY rank with the same ullSamples and moves them itself: one grouped batch of RCCL sends root -> owners, the
+ * filters, one grouped batch owners -> root.  With ulWorld == 1 nothing is moved and librccl is never loaded.
+ * Bootstrap: rank 0 calls if_fir_mc_unique_id(), the host program hands the 128 bytes to the other ranks by whatever
+ * means it has (MPI, a socket, torch.distributed, a file), every rank passes them to if_fir_mc_init().
+ * Errors: 0 + if_fir_mc_last_error(); the context stays valid.  Not re-entrant per context. */
+typedef struct if_fir_mc_ctx if_fir_mc_ctx_t;
+#define IF_FIR_MC_ID_BYTES 128u
+
+uint32_t if_fir_mc_owner(uint32_t ulChannel, uint32_t ulWorld);
+uint8_t if_fir_mc_unique_id(uint8_t *pubId /* IF_FIR_MC_ID_BYTES */);
+/* pfTaps: ulChannels rows of ulTaps real float32 taps.  ullMaxSamples > 0: per-call limit (sizes the staging buffers
+ * of the ranks other than 0).  pubId may be NULL when ulWorld == 1. */
+uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, const float *pfTaps, uint32_t ulTaps,
+                       uint32_t ulDecimation, uint64_t ullMaxSamples, int32_t lDevice, uint32_t ulRank,
+                       uint32_t ulWorld, const uint8_t *pubId);
+void if_fir_mc_destroy(if_fir_mc_ctx_t *pCtx);
+uint8_t if_fir_mc_reset(if_fir_mc_ctx_t *pCtx);
+/* all channels take IF_FIR_INPUT_F32 or IF_FIR_INPUT_I16 samples (every rank must make the same call) */
+uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ulFormat);
+/* rank 0: ppDevIn[c] / ppDevOut[c] = device pointers on rank 0's GPU for every channel; other ranks may pass NULL.
+ * Synchronous: returns when this rank's part (transfers and filters) has finished.  *pullOutSamples: per channel. */
+uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDevIn, void *const *ppDevOut,
+                                 uint64_t ullSamples, uint64_t *pullOutSamples);
+/* the single-channel context behind a channel this rank owns (NULL otherwise), e.g. for if_fir_set_backend() */
+if_fir_ctx_t *if_fir_mc_channel_ctx(if_fir_mc_ctx_t *pCtx, uint32_t ulChannel);
+const char *if_fir_mc_last_error(const if_fir_mc_ctx_t *pCtx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,10 @@ EXPORTS = [
     "if_fir_set_tuning", "if_fir_set_input_format", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
+    "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
+    "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
 ]
+MC_ID_BYTES = 128
 
 
 class IfFirError(RuntimeError):
@@ -87,6 +90,25 @@ def lib():
     L.if_fir_debug_stamps.restype = u32
     L.if_fir_device_info.argtypes = [vp, ctypes.c_char_p, u32]
     L.if_fir_device_info.restype = u8
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    L.if_fir_mc_owner.argtypes = [u32, u32]
+    L.if_fir_mc_owner.restype = u32
+    L.if_fir_mc_unique_id.argtypes = [u8p]
+    L.if_fir_mc_unique_id.restype = u8
+    L.if_fir_mc_init.argtypes = [ctypes.POINTER(vp), u32, f32p, u32, u32, u64, i32, u32, u32, u8p]
+    L.if_fir_mc_init.restype = u8
+    L.if_fir_mc_destroy.argtypes = [vp]
+    L.if_fir_mc_destroy.restype = None
+    L.if_fir_mc_reset.argtypes = [vp]
+    L.if_fir_mc_reset.restype = u8
+    L.if_fir_mc_set_input_format.argtypes = [vp, u32]
+    L.if_fir_mc_set_input_format.restype = u8
+    L.if_fir_mc_process_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), u64, ctypes.POINTER(u64)]
+    L.if_fir_mc_process_device.restype = u8
+    L.if_fir_mc_channel_ctx.argtypes = [vp, u32]
+    L.if_fir_mc_channel_ctx.restype = vp
+    L.if_fir_mc_last_error.argtypes = [vp]
+    L.if_fir_mc_last_error.restype = ctypes.c_char_p
     _lib = L
     return L
 
@@ -250,3 +272,84 @@ class IfFir:
         self._check(lib().if_fir_dev_download(self._ctx, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
                                               host.nbytes))
         return host
+
+
+def mc_owner(channel, world):
+    """if_fir_mc_owner(): the rank that filters a channel (channel mod world)."""
+    return int(lib().if_fir_mc_owner(int(channel), int(world)))
+
+
+def mc_unique_id():
+    """if_fir_mc_unique_id(): rank 0's RCCL bootstrap id (128 bytes) to hand to the other ranks."""
+    buf = (ctypes.c_uint8 * MC_ID_BYTES)()
+    if not lib().if_fir_mc_unique_id(buf):
+        raise IfFirError(lib().if_fir_mc_last_error(None).decode())
+    return bytes(buf)
+
+
+class IfFirMc:
+    """One if_fir_mc_ctx_t: channel c -> rank c mod world, inputs/outputs on rank 0's GPU (see include/if_fir.h)."""
+
+    def __init__(self, taps, decimation, max_samples, device=0, rank=0, world=1, unique_id=None):
+        taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float32))
+        if taps.ndim != 2:
+            raise IfFirError("taps must be a (channels, taps) array")
+        self.channels, self.rank, self.world = int(taps.shape[0]), int(rank), int(world)
+        self._ctx = ctypes.c_void_p(None)
+        idbuf = None
+        if unique_id is not None:
+            idbuf = (ctypes.c_uint8 * MC_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        ok = lib().if_fir_mc_init(ctypes.byref(self._ctx), self.channels, _f32p(taps), int(taps.shape[1]),
+                                  int(decimation), int(max_samples), int(device), self.rank, self.world, idbuf)
+        if not ok:
+            self._ctx = ctypes.c_void_p(None)
+            raise IfFirError(lib().if_fir_mc_last_error(None).decode())
+
+    def _check(self, ok):
+        if not ok:
+            raise IfFirError(lib().if_fir_mc_last_error(self._ctx).decode())
+
+    def reset(self):
+        self._check(lib().if_fir_mc_reset(self._ctx))
+
+    def set_input_format(self, fmt):
+        self._check(lib().if_fir_mc_set_input_format(self._ctx, int(fmt)))
+
+    def channel_ctx(self, channel):
+        """Raw if_fir_ctx_t* (int) of a channel this rank owns, else None."""
+        return lib().if_fir_mc_channel_ctx(self._ctx, int(channel))
+
+    def set_backend(self, backend):
+        """if_fir_set_backend() on every channel this rank owns."""
+        for c in range(self.channels):
+            h = self.channel_ctx(c)
+            if h and not lib().if_fir_set_backend(h, int(backend)):
+                raise IfFirError(lib().if_fir_last_error(h).decode())
+
+    def process_device(self, dev_in, dev_out, samples):
+        """if_fir_mc_process_device(): lists of device pointers (ints) on rank 0, None elsewhere.  Returns the
+        per-channel output sample count."""
+        m = ctypes.c_uint64(0)
+        pin = pout = None
+        if dev_in is not None:
+            pin = (ctypes.c_void_p * self.channels)(*[ctypes.c_void_p(int(p)) for p in dev_in])
+            pout = (ctypes.c_void_p * self.channels)(*[ctypes.c_void_p(int(p)) for p in dev_out])
+        self._check(lib().if_fir_mc_process_device(self._ctx, pin, pout, int(samples), ctypes.byref(m)))
+        return int(m.value)
+
+    def close(self):
+        if self._ctx:
+            lib().if_fir_mc_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -431,3 +431,54 @@ def test_int16_input_front_end(fir, oracle, t, d):
         with pytest.raises(fir.IfFirError):
             f.set_input_format(fir.INPUT_I16)        # forced real-only backend: format refused, context usable
         assert f.process(xf).size == 2 * oracle.out_count(0, n, d)
+
+
+def test_multi_channel_front_one_rank(fir, oracle, torch_cuda):
+    """if_fir_mc_* with world = 1: three channels with their own taps and their own streaming state on one GPU, device
+    pointer arrays in and out, two calls (history carried per channel); no RCCL is loaded on this path."""
+    torch = torch_cuda
+    n, d, t = 70_001, 4, 255
+    bands = [(0.15, 0.25), (0.02, 0.08), (0.30, 0.45)]
+    taps = np.stack([fir.bpf_design(t, lo, hi) for lo, hi in bands])
+    xs = [oracle.synth_iq(n, 30 + c) for c in range(3)]
+    dev_in = [torch.from_numpy(x).cuda() for x in xs]
+    cuts = [0, 30_003, n]
+    with fir.IfFirMc(taps, d, n) as mc:
+        assert [fir.mc_owner(c, 1) for c in range(3)] == [0, 0, 0]
+        assert all(mc.channel_ctx(c) for c in range(3)) and mc.channel_ctx(3) is None
+        for backend, exact in ((fir.BACKEND_HIP_DIRECT, True), (fir.BACKEND_AUTO, False)):
+            mc.set_backend(backend)
+            mc.reset()
+            parts = [[] for _ in range(3)]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                m_exp = oracle.out_count(a, b - a, d)
+                outs = [torch.full((2 * m_exp + 8,), 7.0, dtype=torch.float32, device="cuda") for _ in range(3)]
+                tails = [x[2 * a:2 * b].clone() for x in dev_in]       # 16-byte aligned pieces
+                torch.cuda.synchronize()
+                m = mc.process_device([p.data_ptr() for p in tails], [o.data_ptr() for o in outs], b - a)
+                assert m == m_exp
+                for c in range(3):
+                    o = outs[c].cpu().numpy()
+                    assert np.all(o[2 * m:] == 7.0)                    # nothing written past the outputs
+                    parts[c].append(o[:2 * m])
+            for c in range(3):
+                y = np.concatenate(parts[c])
+                if exact:
+                    assert np.array_equal(y, oracle.fir_f32fma(taps[c], xs[c], d, **SEG))
+                l2, mx = oracle.err_metrics(y, oracle.fir_f64(taps[c], xs[c], d))
+                assert l2 <= TOL and mx <= TOL, (c, l2, mx)
+        with pytest.raises(fir.IfFirError, match="exceed"):
+            mc.process_device([p.data_ptr() for p in dev_in], [p.data_ptr() for p in dev_in], n + 1)
+        with pytest.raises(fir.IfFirError, match="rank 0 must pass"):
+            mc.process_device(None, None, 16)
+        mc.reset()                                                     # still usable after the errors
+        out = torch.empty(2 * oracle.out_count(0, 64, d), dtype=torch.float32, device="cuda")
+        outs = [out, out.clone(), out.clone()]
+        assert mc.process_device([p.data_ptr() for p in dev_in], [o.data_ptr() for o in outs], 64) == 16
+
+
+def test_multi_channel_bootstrap_id(fir, gpu_ok):
+    """if_fir_mc_unique_id(): librccl is opened on demand and hands out a bootstrap id (the >1-rank transfers need
+    more than the one GPU of this box; their rank/peer bookkeeping is the same c mod world rule the gloo tests cover)."""
+    a, b = fir.mc_unique_id(), fir.mc_unique_id()
+    assert len(a) == fir.MC_ID_BYTES and any(a) and a != b

@@ -75,3 +75,22 @@ def test_generated_walk_header_is_current():
     subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_walk.py"), "--out", out])
     committed = open(os.path.join(ROOT, "qo-100-tools_amd", "csrc", "generated", "if_fir_walk_gen.h")).read()
     assert open(out).read() == committed
+
+
+def test_mc_owner_matches_channel_map_and_init_argument_errors(fir):
+    """The multi-channel C front (if_fir_mc_*): ownership rule = channel_shard.channel_map, and the argument checks that
+    need no GPU fail with a message instead of touching a device."""
+    import __graft_entry__ as g
+    cs = g.load_pkg().channel_shard
+    for world in (1, 2, 3, 8):
+        cmap = cs.channel_map(8, world)
+        for rank, chans in enumerate(cmap):
+            for c in chans:
+                assert fir.mc_owner(c, world) == rank
+    taps = np.stack([fir.bpf_design(31), fir.bpf_design(31, 0.05, 0.1)])
+    with pytest.raises(fir.IfFirError, match="invalid argument"):
+        fir.IfFirMc(taps, 1, 0)                                   # max samples must be > 0
+    with pytest.raises(fir.IfFirError, match="invalid argument"):
+        fir.IfFirMc(taps, 1, 1000, rank=2, world=2)               # rank out of range
+    with pytest.raises(fir.IfFirError, match="unique id"):
+        fir.IfFirMc(taps, 1, 1000, rank=0, world=2)               # two ranks without the bootstrap id

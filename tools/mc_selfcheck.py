@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""mc_selfcheck.py — exercises if_fir_mc_* across ranks on a multi-GPU node (not runnable on the one-GPU box).
+
+launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        tools/mc_selfcheck.py [channels] [log2 samples]
+Rank 0 synthesises every channel on its GPU, all ranks call if_fir_mc_process_device() twice (streaming state per
+channel), rank 0 compares every channel with a single-channel context run locally on the same input and prints the
+scatter+filter+gather time.  The RCCL bootstrap id travels through torch.distributed (any other transport would do).
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import __graft_entry__ as g  # noqa: E402
+
+
+def main():
+    channels = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 24)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    fir = g.load_pkg().if_fir
+    uid = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        idt = torch.zeros(fir.MC_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(fir.mc_unique_id()), dtype=torch.uint8).cuda()
+        dist.broadcast(idt, 0)
+        uid = bytes(idt.cpu().numpy().tobytes())
+    d, t = 4, 255
+    taps = np.stack([fir.bpf_design(t, 0.02 + 0.05 * c, 0.06 + 0.05 * c) for c in range(channels)])
+    with fir.IfFirMc(taps, d, n, device=local, rank=rank, world=world, unique_id=uid) as mc:
+        ins = outs = None
+        if rank == 0:
+            with fir.IfFir(taps[0], d, 0, device=local) as f:
+                ins = [torch.empty(2 * n, dtype=torch.float32, device="cuda") for _ in range(channels)]
+                for c in range(channels):
+                    f.synth_device(ins[c].data_ptr(), 0, n, c)
+                f.synchronize()
+                m = f.out_count(n)
+            outs = [torch.zeros(2 * m, dtype=torch.float32, device="cuda") for _ in range(channels)]
+            torch.cuda.synchronize()
+        ok = True
+        for call in range(2):
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            got = mc.process_device([x.data_ptr() for x in ins] if rank == 0 else None,
+                                    [y.data_ptr() for y in outs] if rank == 0 else None, n)
+            dt = time.perf_counter() - t0
+            if rank == 0:
+                assert got == m
+                for c in range(channels):
+                    with fir.IfFir(taps[c], d, 0, device=local) as f:
+                        ref = torch.empty_like(outs[c])
+                        for _ in range(call + 1):          # same stream state as channel c after `call` earlier calls
+                            f.process_device(ins[c].data_ptr(), ref.data_ptr(), n)
+                        f.synchronize()
+                    same = bool(torch.equal(ref, outs[c]))
+                    ok = ok and same
+                    if not same:
+                        print("call %d channel %d (rank %d): MISMATCH max |diff| %g" %
+                              (call, c, fir.mc_owner(c, world), (ref - outs[c]).abs().max().item()))
+                print("call %d: %d channels x 2^%d samples over %d ranks: %.2f ms (%.1f GS/s end to end) %s" %
+                      (call, channels, int(np.log2(n)), world, dt * 1e3, channels * n / dt / 1e9, "OK" if ok else "FAIL"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
