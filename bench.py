@@ -36,6 +36,7 @@ WORKLOADS = {
     "fir255_2p28": (255, 1, 28, "255-tap complex-IQ FIR, no decimation, one channel per GPU, 2^28 IQ samples"),
     "fir255_dec4_2p24": (255, 4, 24, "255-tap + decimate-by-4, 2^24 IQ samples (quick check size)"),
     "fir255_dec4_i16_2p28": (255, 4, 28, "255-tap FIR + decimate-by-4, int16 IQ input front-end (SURVEY §8f-1), 2^28 samples"),
+    "fir255_dec4_nco_2p28": (255, 4, 28, "NCO mix (0.19995 cycles/sample) fused into the 255-tap FIR + decimate-by-4 (SURVEY §8f-1), 2^28 samples"),
     "fir2047_dec8_2p26": (2047, 8, 26, "2047-tap FIR, decimate-by-8, 2^26 IQ samples (tap-split kernel territory)"),
     "fir1023_2p28": (1023, 1, 28, "1023-tap complex-IQ FIR, one channel per GPU, 2^28 IQ samples (BASELINE configs[4])"),
 }
@@ -45,12 +46,12 @@ def algorithmic_bytes_per_sample(decim, in_bytes=8.0):
     return in_bytes + 8.0 / decim     # read 8 B (4 B for int16 input) per input sample, write 8/D
 
 
-def whole_output_check(fir, f, taps, decim, x, y, n, i16, stream, device, calls, names):
+def whole_output_check(fir, f, taps, decim, x, y, n, i16, stream, device, calls, names, nco=0.0):
     """Every output sample of the timed context's last call against another kernel family: the reference context is
     primed with the tail of x (the timed stream's history: x is fed again every step, n is a multiple of the
     decimation) and filters x once.  Both sides are within 1e-6 of the float64 result, so they agree within 2e-6."""
     run_b = f.get_backend()
-    direct_ok = (not i16) and taps.size in (127, 255) and decim in (1, 4)
+    direct_ok = (not i16) and (not nco) and taps.size in (127, 255) and decim in (1, 4)
     if run_b != fir.BACKEND_HIP_DIRECT and direct_ok:
         ref_b = fir.BACKEND_HIP_DIRECT
     elif run_b != fir.BACKEND_HIP_GENERIC:
@@ -65,6 +66,8 @@ def whole_output_check(fir, f, taps, decim, x, y, n, i16, stream, device, calls,
         fr.set_stream(stream.cuda_stream)
         if i16:
             fr.set_input_format(fir.INPUT_I16)
+        if nco:
+            fr.set_nco(nco)      # bench frequencies satisfy P * tail = 0 (mod 2^32): same phase as the timed stream
         fr.set_backend(ref_b)
         yref = torch.empty_like(y)
         if calls > 1:
@@ -172,6 +175,9 @@ def main():
     taps_n, decim, log2n, desc = WORKLOADS[args.workload]
     n = 1 << log2n
     i16 = "_i16_" in args.workload
+    # NCO workload: a frequency whose phase word is a multiple of 2^19, so that P * 8192 = 0 mod 2^32 and the
+    # whole-output check can reproduce the timed context's phase from a short priming call
+    nco = 1638.0 / 8192.0 if "_nco_" in args.workload else 0.0
     in_bytes = 4.0 if i16 else 8.0
     taps = fir.bpf_design(taps_n)
     backend_ids = {"auto": fir.BACKEND_AUTO, "direct": fir.BACKEND_HIP_DIRECT, "fft": fir.BACKEND_HIP_FFT,
@@ -179,6 +185,8 @@ def main():
     f = fir.IfFir(taps, decim, 0, device=local_rank, backend=backend_ids[args.backend])
     if args.variant is not None:
         f.set_tuning(args.variant)
+    if nco:
+        f.set_nco(nco)
     stream = torch.cuda.Stream(device=dev)   # a real (non-null) HIP stream: handle 0 would mean "context's own stream"
     torch.cuda.set_stream(stream)
     f.set_stream(stream.cuda_stream)         # kernels run on this stream so the torch.cuda.Event pair brackets them
@@ -236,7 +244,8 @@ def main():
     names = {1: "hip_direct", 2: "hip_tapsplit", 3: "hip_generic", 4: "hip_fft"}
     # whole-output check of the TIMED context's last step against a different kernel family in the same stream state
     # (a work-distribution bug that leaves blocks unwritten makes a launch look fast; windows do not see it)
-    whole = whole_output_check(fir, f, taps, decim, x, y, n, i16, stream, local_rank, args.warmup + args.steps, names)
+    whole = whole_output_check(fir, f, taps, decim, x, y, n, i16, stream, local_rank, args.warmup + args.steps, names,
+                               nco)
     if use_dist:
         okt = torch.tensor([1.0 if whole["ok"] else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
@@ -251,7 +260,7 @@ def main():
             dist.destroy_process_group()
         sys.exit(1)
     if rank == 0 and args.backend == "auto" and f.get_backend() == fir.BACKEND_HIP_FFT and taps_n in (127, 255) \
-            and decim in (1, 4) and not i16:
+            and decim in (1, 4) and not i16 and not nco:
         # the north_star's direct-form MAC kernel, timed beside the default overlap-save path (same buffers, same
         # stream; not part of `value`)
         f.set_backend(fir.BACKEND_HIP_DIRECT)
@@ -329,6 +338,8 @@ def main():
             f2.set_input_format(fir.INPUT_I16)
         if args.variant is not None:
             f2.set_tuning(args.variant)
+        if nco:
+            f2.set_nco(nco)
         head = 1 << 16
         yh = torch.empty(2 * f2.out_count(head), dtype=torch.float32, device=dev)
         f2.process_device(x.data_ptr(), yh.data_ptr(), head)
@@ -336,10 +347,11 @@ def main():
         xh = x[:2 * head].cpu().numpy()
         if i16:
             xh = xh.astype(np.float32) * np.float32(2.0 ** -15)
-        l2, mx = oracle.err_metrics(yh.cpu().numpy(), oracle.fir_f64(taps, xh, decim))
+        ref64 = oracle.fir_nco_f64(taps, xh, decim, oracle.nco_phase_word(nco)) if nco else oracle.fir_f64(taps, xh, decim)
+        l2, mx = oracle.err_metrics(yh.cpu().numpy(), ref64)
         parity = {"rel_l2_vs_f64_oracle": l2, "rel_max_vs_f64_oracle": mx, "tolerance": 1e-6,
                   "window": "first 2^16 input samples", "whole_output": whole}
-        if f2.get_backend() in (fir.BACKEND_HIP_DIRECT, fir.BACKEND_HIP_GENERIC):
+        if f2.get_backend() in (fir.BACKEND_HIP_DIRECT, fir.BACKEND_HIP_GENERIC) and not nco:
             model = oracle.fir_f32fma(taps, xh, decim, seg_mode=1, seg_len=32)
             parity["bit_exact_vs_f32_order_model"] = bool(np.array_equal(yh.cpu().numpy(), model))
         f2.close()

@@ -92,6 +92,12 @@ uint32_t if_fir_get_backend(const if_fir_ctx_t *pCtx); /* the resolved (non-AUTO
 /* Input sample format: IF_FIR_INPUT_F32 (default) or IF_FIR_INPUT_I16 (pfIQIn / pDevIn then point at int16 pairs; the
  * conversion is fused into the kernels' loads; overlap-save and generic backends).  Outputs stay float32. */
 uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat);
+/* NCO fused into the filter (docs/SPEC.md §3.2): the input is mixed with exp(-j*2*pi*f*a), a = absolute
+ * sample index since init/reset, f quantised to a 32-bit phase word (if_fir_get_nco returns the value applied).
+ * dFreq in cycles/sample, |dFreq| <= 0.5; 0 switches the NCO off.  Takes effect from the next call, as if it had been
+ * set since the last reset (the phase is a function of the absolute index).  Overlap-save and generic kernels only. */
+uint8_t if_fir_set_nco(if_fir_ctx_t *pCtx, double dFreq);
+uint8_t if_fir_get_nco(const if_fir_ctx_t *pCtx, double *pdFreq);
 /* expert knob: pick a tuning variant of the resolved backend's kernel (0 = default).  Also settable
  * with the environment variable IF_FIR_VARIANT read at if_fir_init. */
 uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant);

@@ -444,6 +444,53 @@ ORACLE_API uint64_t oracle_fir_c64_ctaps_f64(const float *pfTapsIQ, uint32_t T, 
     return M;
 }
 
+/* NCO + FIR by the definition (docs/SPEC.md §3.2): every input sample with absolute index a is multiplied by         */
+/* exp(-j*2*pi*((P*a) mod 2^32)/2^32) in float64, then filtered (real or complex float32 taps) and decimated.        */
+/* Samples before the start of the stream (a < 0) are zero, so the history is only consulted for a >= 0.            */
+ORACLE_API uint64_t oracle_fir_c64_nco_f64(const float *pfTaps, uint32_t T, uint32_t bComplexTaps, uint32_t D,
+                                          const float *pfHist, uint64_t ullConsumed, const float *pfIn, uint64_t N,
+                                          uint32_t ulPhaseWord, double *pdOut)
+{
+    const uint64_t M = oracle_out_count(ullConsumed, N, D);
+    const int64_t n0 = (int64_t)((D - ullConsumed % D) % D);
+    const int64_t lead = (int64_t)T - 1;
+    double *pdMixed = (double *)malloc(sizeof(double) * 2 * (size_t)(N + (uint64_t)lead + 1));
+
+    if (!pdMixed)
+        return 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t j = -lead; j < (int64_t)N; j++)
+    {
+        float xr, xi;
+        const int64_t a = (int64_t)ullConsumed + j;
+        oracle_fetch(pfHist, T, pfIn, j, &xr, &xi);
+        if (a < 0)
+            xr = xi = 0.0f;
+        const uint32_t ph = (uint32_t)((uint64_t)ulPhaseWord * (uint64_t)a);
+        const double ang = -6.283185307179586476925286766559 * ((double)ph / 4294967296.0);
+        const double c = cos(ang), s = sin(ang);
+        pdMixed[2 * (j + lead)] = (double)xr * c - (double)xi * s;
+        pdMixed[2 * (j + lead) + 1] = (double)xr * s + (double)xi * c;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < (int64_t)M; m++)
+    {
+        const int64_t n = n0 + m * (int64_t)D;
+        double ar = 0.0, ai = 0.0;
+        for (uint32_t k = 0; k < T; k++)
+        {
+            const double xr = pdMixed[2 * (n - (int64_t)k + lead)], xi = pdMixed[2 * (n - (int64_t)k + lead) + 1];
+            const double hr = bComplexTaps ? pfTaps[2 * k] : pfTaps[k], hi = bComplexTaps ? pfTaps[2 * k + 1] : 0.0;
+            ar += xr * hr - xi * hi;
+            ai += xr * hi + xi * hr;
+        }
+        pdOut[2 * m] = ar;
+        pdOut[2 * m + 1] = ai;
+    }
+    free(pdMixed);
+    return M;
+}
+
 /* float32 order model of the generic kernel with complex taps: descending k, segments of L taps [sL,(s+1)L) added  */
 /* as they complete; per tap  re = fma(-xi, hi, fma(xr, hr, re)),  im = fma(xi, hr, fma(xr, hi, im)).                 */
 ORACLE_API uint64_t oracle_fir_c64_ctaps_f32fma(const float *pfTapsIQ, uint32_t T, uint32_t D, const float *pfHist,

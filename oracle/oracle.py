@@ -49,6 +49,8 @@ def _bind(lib):
     lib.oracle_bpf_design_complex.restype = ctypes.c_int
     lib.oracle_fir_c64_ctaps_f64.argtypes = [_f32p, u32, u32, _f32p, u64, _f32p, u64, _f64p]
     lib.oracle_fir_c64_ctaps_f64.restype = u64
+    lib.oracle_fir_c64_nco_f64.argtypes = [_f32p, u32, u32, u32, _f32p, u64, _f32p, u64, u32, _f64p]
+    lib.oracle_fir_c64_nco_f64.restype = u64
     lib.oracle_fir_c64_ctaps_f32fma.argtypes = [_f32p, u32, u32, _f32p, u64, _f32p, u64, _f32p, u32]
     lib.oracle_fir_c64_ctaps_f32fma.restype = u64
     lib.oracle_max_threads.restype = i32
@@ -213,6 +215,24 @@ def fir_ctaps_f64(ctaps, x, decim=1, hist=None, consumed=0):
     m = out_count(consumed, n, decim)
     y = np.empty(2 * m, dtype=np.float64)
     assert lib().oracle_fir_c64_ctaps_f64(_p32(ctaps), t, decim, _p32(hist), consumed, _p32(x), n, _p64(y)) == m
+    return y
+
+
+def nco_phase_word(freq):
+    """SPEC §3.2: P = round(f * 2^32) mod 2^32."""
+    return int(round(float(freq) * 4294967296.0)) % (1 << 32)
+
+
+def fir_nco_f64(taps, x, decim, phase_word, hist=None, consumed=0, complex_taps=False):
+    """float64 oracle of NCO mix + FIR + decimation by the definition (SPEC §3.2); hist holds UNMIXED samples."""
+    taps = _iq(taps) if complex_taps else np.ascontiguousarray(taps, dtype=np.float32)
+    x = _iq(x)
+    n, t = x.size // 2, (taps.size // 2 if complex_taps else taps.size)
+    hist = None if hist is None else _iq(hist)
+    m = out_count(consumed, n, decim)
+    y = np.empty(2 * m, dtype=np.float64)
+    assert lib().oracle_fir_c64_nco_f64(_p32(taps), t, 1 if complex_taps else 0, decim, _p32(hist), consumed, _p32(x),
+                                        n, int(phase_word), _p64(y)) == m
     return y
 
 

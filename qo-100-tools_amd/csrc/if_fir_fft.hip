@@ -159,7 +159,7 @@ constexpr int XREG = 16 * XROW + 32;  // one 16x16 region (+32 so that the 4 reg
 constexpr int XBUF = 4 * XREG;        // per-wave exchange buffer
 constexpr int FFT_WAVES = 8;
 constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_TWD = 65536 + 2048, LDS_TWE = LDS_TWD + 8192,
-              LDS_XB = LDS_TWE + 8192;
+              LDS_NCO = LDS_TWE + 8192, LDS_XB = LDS_NCO + 512;
 static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 constexpr int FFT_LDS_BYTES = LDS_XB + FFT_WAVES * XBUF;
 
@@ -330,12 +330,13 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
     fft16<true>(c); // over k0 -> mu0
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16>
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
                                                         int32_t waves_total, int32_t RA, int32_t nA, int32_t RB, int32_t nB,
-                                                        unsigned int *queue, unsigned long long *dbg, int32_t diag)
+                                                        unsigned int *queue, unsigned long long *dbg, int32_t diag,
+                                                        uint32_t nco_phi0, uint32_t nco_delta)
 {
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
@@ -360,6 +361,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     const f2v *tw2 = reinterpret_cast<const f2v *>(smem + LDS_TW2);
     const f2v *twd = reinterpret_cast<const f2v *>(smem + LDS_TWD);
     const f2v *twe = reinterpret_cast<const f2v *>(smem + LDS_TWE);
+    const f2v *ncob = reinterpret_cast<const f2v *>(smem + LDS_NCO); // NCO: phasor of output row r of a block
+    (void)ncob;
     char *xb = smem + LDS_XB + wid * XBUF;
     (void)twd;
     (void)twe;
@@ -562,6 +565,15 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         load_row<I16>(r, rw, nsrd, lane, phys(i, j));
             }
             constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
+            if constexpr (NCO)
+            {
+                // SPEC §3.2: output m = obase + 64 r + lane is rotated by phasor(phi0 + delta m) = A(lane) * B(r)
+                const float2 pa = nco_phasor(nco_phi0 + nco_delta * ((uint32_t)obase + (uint32_t)lane));
+                const cf a_lane = {pa.x, pa.y};
+#pragma unroll
+                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    c[mu0] = cmul_v<false>(c[mu0], cmul_v<false>(a_lane, ncob[mu0 - MU0_FIRST]));
+            }
 #pragma unroll
             for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
                 buf_store(osrd, voff, (mu0 - MU0_FIRST) * 512, c[mu0]);
@@ -604,6 +616,13 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     r[phys(i, j)] = t[j];
                 }
             exchange1_inv(r);
+            cf a_lane = {1.0f, 0.0f};
+            if constexpr (NCO)
+            {
+                const float2 pa = nco_phasor(nco_phi0 + nco_delta * ((uint32_t)obase + (uint32_t)lane));
+                a_lane = (cf){pa.x, pa.y};
+            }
+            (void)a_lane;
             // ---- last inverse pass, group by group: finish 16 rows, store them, and refill the same registers with
             //      the next block's rows (the loads fly while the remaining groups and the next forward pass compute)
 #pragma unroll
@@ -624,7 +643,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
                     const int row = 4 * j + rho;
                     if (row >= OVL_ROWS)
+                    {
+                        if constexpr (NCO)
+                            t[j] = cmul_v<false>(t[j], cmul_v<false>(a_lane, ncob[row - OVL_ROWS]));
                         buf_store(osrd, voff, (row - OVL_ROWS) * 512, t[j]);
+                    }
                 }
                 if (next_fast)
                 {
@@ -641,10 +664,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     }
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16>
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO>
 static hipError_t launch_fft_t(const LaunchArgs &a)
 {
-    auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16>;
+    auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
     constexpr int LOUT = DEC4 ? L / 4 : L;
     static bool attr_done[16] = {false};
@@ -691,7 +714,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist), a.T, a.N,
                        a.n0, a.M, nblocks, (int32_t)(wgs * FFT_WAVES), (int32_t)RA, (int32_t)nA, (int32_t)RB, (int32_t)nB,
                        (unsigned int *)a.queue,
-                       (unsigned long long *)a.dbg, (int32_t)a.diag);
+                       (unsigned long long *)a.dbg, (int32_t)a.diag, nco_phi0(a), nco_delta(a));
     return hipGetLastError();
 }
 
@@ -709,16 +732,31 @@ hipError_t launch_fft(const LaunchArgs &a)
 {
     if (!fft_supported(a.T, a.D) || !a.fft_tables)
         return hipErrorInvalidConfiguration;
-    const bool small = fft_overlap_rows(a.T) == 4;
-    if (a.in_i16)
+    const int key = (fft_overlap_rows(a.T) == 4 ? 0 : 8) | (a.D == 4 ? 4 : 0) | (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
+    switch (key)
     {
-        if (a.D == 4)
-            return small ? launch_fft_t<4, true, true>(a) : launch_fft_t<16, true, true>(a);
-        return small ? launch_fft_t<4, false, true>(a) : launch_fft_t<16, false, true>(a);
+#define IF_FIR_FFT_CASE(K_, ROWS_, DEC_, I16_, NCO_) \
+    case K_:                                         \
+        return launch_fft_t<ROWS_, DEC_, I16_, NCO_>(a)
+        IF_FIR_FFT_CASE(0, 4, false, false, false);
+        IF_FIR_FFT_CASE(1, 4, false, false, true);
+        IF_FIR_FFT_CASE(2, 4, false, true, false);
+        IF_FIR_FFT_CASE(3, 4, false, true, true);
+        IF_FIR_FFT_CASE(4, 4, true, false, false);
+        IF_FIR_FFT_CASE(5, 4, true, false, true);
+        IF_FIR_FFT_CASE(6, 4, true, true, false);
+        IF_FIR_FFT_CASE(7, 4, true, true, true);
+        IF_FIR_FFT_CASE(8, 16, false, false, false);
+        IF_FIR_FFT_CASE(9, 16, false, false, true);
+        IF_FIR_FFT_CASE(10, 16, false, true, false);
+        IF_FIR_FFT_CASE(11, 16, false, true, true);
+        IF_FIR_FFT_CASE(12, 16, true, false, false);
+        IF_FIR_FFT_CASE(13, 16, true, false, true);
+        IF_FIR_FFT_CASE(14, 16, true, true, false);
+        IF_FIR_FFT_CASE(15, 16, true, true, true);
+#undef IF_FIR_FFT_CASE
     }
-    if (a.D == 4)
-        return small ? launch_fft_t<4, true, false>(a) : launch_fft_t<16, true, false>(a);
-    return small ? launch_fft_t<4, false, false>(a) : launch_fft_t<16, false, false>(a);
+    return hipErrorInvalidConfiguration;
 }
 
 // Host side: twiddle and H tables in the kernel's LDS image order (float64 math, rounded once to float32).
@@ -726,11 +764,20 @@ hipError_t launch_fft(const LaunchArgs &a)
 //   [32 KB, 64 KB)  hp [(i*16+k2)*64 + lane]   = FFT(taps)[(4*(lane/16)+i) + 16*(lane%16) + 256*k2] / 4096
 //   [64 KB, 66 KB)  tw2[k1*16 + n2]            = W256^(n2*k1)
 //   [66 KB, 82 KB)  twd, twe: twiddles of the decimate-by-4 1024-point inverse
-void fft_build_tables(const float *taps, int T, int ctaps, int D, float *tables /* FFT_TABLE_FLOATS floats */)
+void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta,
+                      float *tables /* FFT_TABLE_FLOATS floats */)
 {
     const double PI2 = 6.283185307179586476925286766559;
     float *tw1 = tables, *hp = tables + 2 * 4096, *tw2 = tables + 4 * 4096;
-    float *twd = tw2 + 2 * 256, *twe = twd + 2 * 1024;
+    float *twd = tw2 + 2 * 256, *twe = twd + 2 * 1024, *ncob = twe + 2 * 1024;
+    // NCO (SPEC §3.2): rotation shared by the 64 outputs of row r of a block, exp(+j*2*pi*((64 r delta) mod 2^32)/2^32)
+    for (uint32_t r = 0; r < 64; r++)
+    {
+        const uint32_t ph = 64u * r * nco_delta;
+        const double a = PI2 * ((double)ph / 4294967296.0);
+        ncob[2 * r + 0] = (float)cos(a);
+        ncob[2 * r + 1] = (float)sin(a);
+    }
     // decimate-by-4 inverse: twd[(i*4+mu2)*64 + lane] = W1024^((16*(lane%16) + 4*(lane/16) + i)*mu2)
     //                        twe[mu1*64 + lane]       = W256^((4*(lane/16) + (lane%16)/4)*mu1)
     for (int i = 0; i < 4; i++)

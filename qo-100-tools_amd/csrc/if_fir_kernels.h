@@ -35,15 +35,33 @@ struct LaunchArgs
     int diag;  // development diagnostics for the FFT kernel (0 in production)
     int grid_limit; // FFT backend: at most this many workgroups (0 = one per CU); same results, used by the queue tests
     void *dbg; // optional diagnostic stamp buffer (8192 x 4 x u64) or nullptr
+    uint32_t nco_word; // SPEC §3.2 phase word P (0 = no NCO); taps are then the complex g[k] = h[k] e^{+j theta k}
+    uint32_t nco_abs0; // absolute index (mod 2^32) of this call's input sample 0
 };
+
+// output m of a call is rotated by exp(+j*2*pi*phi/2^32), phi = nco_phi0 + m * nco_delta (mod 2^32):
+// the input sample under output m has absolute index a = abs0 + n0 + m*D and the NCO phase there is -(P*a)
+inline uint32_t nco_phi0(const LaunchArgs &a) { return 0u - a.nco_word * (a.nco_abs0 + (uint32_t)a.n0); }
+inline uint32_t nco_delta(const LaunchArgs &a) { return 0u - a.nco_word * (uint32_t)a.D; }
+
+#if defined(__HIPCC__)
+// exp(+j*2*pi*ph/2^32) from a 32-bit phase: both sincospif arguments are exact in float32 (16 bits each)
+__device__ __forceinline__ float2 nco_phasor(uint32_t ph)
+{
+    float sh, ch, sl, cl;
+    sincospif((float)(ph >> 16) * (1.0f / 32768.0f), &sh, &ch);
+    sincospif((float)(ph & 0xffffu) * (1.0f / 2147483648.0f), &sl, &cl);
+    return make_float2(fmaf(ch, cl, -sh * sl), fmaf(sh, cl, ch * sl));
+}
+#endif
 
 bool direct_supported(int T, int D);
 hipError_t launch_fir(const LaunchArgs &a, int variant);
 // overlap-save FFT backend (if_fir_fft.hip)
-constexpr int FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024);
+constexpr int FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024 + 64); // ... + 64 NCO row phasors
 bool fft_supported(int T, int D);
 hipError_t launch_fft(const LaunchArgs &a);
-void fft_build_tables(const float *taps, int T, int ctaps, int D, float *tables);
+void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, float *tables);
 
 hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, int in_i16,
                           hipStream_t stream);

@@ -574,7 +574,8 @@ template <int SEG, bool CTAPS, bool I16>
 __global__ __launch_bounds__(256) void fir_generic_kernel(const f2 *__restrict__ in, f2 *__restrict__ out,
                                                          const float *__restrict__ taps,
                                                          const f2 *__restrict__ hist, int T, int D, int64_t N,
-                                                         int32_t n0, int64_t M)
+                                                         int32_t n0, int64_t M, uint32_t nco_on, uint32_t nco_phi0,
+                                                         uint32_t nco_delta)
 {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M)
@@ -602,6 +603,12 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const f2 *__restrict__
         }
         if (k % SEG == 0)
             tot = (k / SEG == top) ? acc : tot + acc;
+    }
+    if (nco_on)
+    {
+        // SPEC §3.2: the NCO ahead of the filter = complex taps (already in `taps`) + this rotation of the output
+        const float2 w = nco_phasor(nco_phi0 + (uint32_t)m * nco_delta);
+        tot = (f2){fmaf(tot.x, w.x, -tot.y * w.y), fmaf(tot.x, w.y, tot.y * w.x)};
     }
     out[m] = tot;
 }
@@ -846,7 +853,8 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
 #define IF_FIR_GENERIC_LAUNCH(CT_, I16_)                                                                          \
     hipLaunchKernelGGL((fir_generic_kernel<32, CT_, I16_>), dim3((unsigned)blocks), dim3(256), 0, a.stream,        \
                        reinterpret_cast<const f2 *>(a.in), reinterpret_cast<f2 *>(a.out), a.taps,                  \
-                       reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M)
+                       reinterpret_cast<const f2 *>(a.hist), a.T, a.D, a.N, a.n0, a.M, a.nco_word, nco_phi0(a),   \
+                       nco_delta(a))
         if (a.ctaps && a.in_i16)
             IF_FIR_GENERIC_LAUNCH(true, true);
         else if (a.ctaps)

@@ -36,7 +36,9 @@ struct if_fir_ctx
     void *d_stage_in;
     void *d_stage_out;
     float tone[10];
-    float *h_taps; // host copy of the taps (FFT tables are built on demand)
+    float *h_taps; // host copy of the caller's taps (FFT tables are built on demand)
+    uint32_t nco_word; // SPEC §3.2 phase word (0 = no NCO)
+    float *h_eff; // NCO on: effective complex taps g[k] = h[k] e^{+j theta k} (2T floats), else nullptr
     void *d_fft_tables; // overlap-save backend tables (built on first use)
     void *d_queue; // atomic run queue of the persistent kernel
     void *d_dbg; // diagnostic wave stamps (if_fir_debug_stamps)
@@ -66,6 +68,10 @@ static void set_err(const if_fir_ctx *ctx, const char *fmt, ...)
         }                                                                                       \
     } while (0)
 
+// taps as the kernels see them: the caller's, or the NCO-shifted complex ones
+static inline int eff_ctaps(const if_fir_ctx *ctx) { return ctx->ctaps || ctx->nco_word; }
+static inline const float *eff_taps(const if_fir_ctx *ctx) { return ctx->h_eff ? ctx->h_eff : ctx->h_taps; }
+
 // AUTO: the fastest backend that meets SPEC §3 — overlap-save for every (T, D) it covers with at least 32 taps
 // (0.58 ms vs 0.85 ms direct on 255 taps /4, 2^28 samples), else the unrolled direct form, else the tap-split kernel
 // (any T, D); the one-output-per-thread generic kernel stays as an independent cross-check
@@ -73,17 +79,17 @@ static uint32_t resolve_backend(const if_fir_ctx *ctx, uint32_t req)
 {
     if (req != IF_FIR_BACKEND_AUTO)
         return req;
-    if (if_fir::fft_supported(ctx->T, ctx->D) && (ctx->T >= 32 || ctx->ctaps || ctx->in_i16))
+    if (if_fir::fft_supported(ctx->T, ctx->D) && (ctx->T >= 32 || eff_ctaps(ctx) || ctx->in_i16))
         return IF_FIR_BACKEND_HIP_FFT;
-    if (ctx->ctaps || ctx->in_i16)
+    if (eff_ctaps(ctx) || ctx->in_i16)
         return IF_FIR_BACKEND_HIP_GENERIC;
     return if_fir::direct_supported(ctx->T, ctx->D) ? IF_FIR_BACKEND_HIP_DIRECT : IF_FIR_BACKEND_HIP_TAPSPLIT;
 }
 
 static bool backend_ok(const if_fir_ctx *ctx, uint32_t b)
 {
-    if ((ctx->ctaps || ctx->in_i16) && b != IF_FIR_BACKEND_HIP_FFT && b != IF_FIR_BACKEND_HIP_GENERIC)
-        return false; // complex taps / int16 input: overlap-save and generic kernels only
+    if ((eff_ctaps(ctx) || ctx->in_i16) && b != IF_FIR_BACKEND_HIP_FFT && b != IF_FIR_BACKEND_HIP_GENERIC)
+        return false; // complex taps / NCO / int16 input: overlap-save and generic kernels only
     switch (b)
     {
     case IF_FIR_BACKEND_HIP_DIRECT:
@@ -109,7 +115,7 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
         set_err(ctx, "overlap-save tables: out of host memory");
         return 0;
     }
-    if_fir::fft_build_tables(ctx->h_taps, ctx->T, ctx->ctaps, ctx->D, tab);
+    if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)ctx->D, tab);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
@@ -278,6 +284,7 @@ IF_FIR_API void if_fir_destroy(if_fir_ctx_t *pCtx)
     if (pCtx->d_fft_tables)
         (void)hipFree(pCtx->d_fft_tables);
     free(pCtx->h_taps);
+    free(pCtx->h_eff);
     delete pCtx;
 }
 
@@ -388,7 +395,9 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.hist = ctx->d_hist[ctx->hist_cur];
     a.T = ctx->T;
     a.D = ctx->D;
-    a.ctaps = ctx->ctaps;
+    a.ctaps = eff_ctaps(ctx);
+    a.nco_word = ctx->nco_word;
+    a.nco_abs0 = (uint32_t)ctx->consumed;
     a.in_i16 = ctx->in_i16;
     a.N = (int64_t)n;
     a.n0 = (int32_t)n0;
@@ -608,6 +617,97 @@ IF_FIR_API uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, u
 // value = int16 * 2^-15, converted inside the kernels' loads (overlap-save and generic backends).  Must be chosen
 // before the first sample is processed (or right after if_fir_reset): the history buffer holds samples in the
 // input format.
+// SPEC §3.2.  The kernels see complex taps g[k] = h[k] e^{+j theta k} and rotate their outputs; nothing else changes.
+IF_FIR_API uint8_t if_fir_set_nco(if_fir_ctx_t *pCtx, double dFreq)
+{
+    if (!pCtx)
+        return 0;
+    if (!std::isfinite(dFreq) || std::fabs(dFreq) > 0.5)
+    {
+        set_err(pCtx, "if_fir_set_nco: frequency must be within +-0.5 cycles/sample (got %g)", dFreq);
+        return 0;
+    }
+    const uint32_t word = (uint32_t)(int64_t)std::llround(dFreq * 4294967296.0); // mod 2^32 (two's complement)
+    if (word == pCtx->nco_word)
+        return 1;
+    const uint32_t T = (uint32_t)pCtx->T;
+    float *eff = nullptr;
+    if (word)
+    {
+        eff = (float *)malloc(sizeof(float) * 2 * T);
+        if (!eff)
+        {
+            set_err(pCtx, "if_fir_set_nco: out of host memory");
+            return 0;
+        }
+        for (uint32_t k = 0; k < T; k++)
+        {
+            const double a = 6.283185307179586476925286766559 * ((double)(uint32_t)(word * k) / 4294967296.0);
+            const double hr = pCtx->ctaps ? (double)pCtx->h_taps[2 * k] : (double)pCtx->h_taps[k];
+            const double hi = pCtx->ctaps ? (double)pCtx->h_taps[2 * k + 1] : 0.0;
+            eff[2 * k + 0] = (float)(hr * cos(a) - hi * sin(a));
+            eff[2 * k + 1] = (float)(hr * sin(a) + hi * cos(a));
+        }
+    }
+    // would the requested backend still apply?  (decide before anything is changed)
+    const uint32_t old_word = pCtx->nco_word;
+    float *old_eff = pCtx->h_eff;
+    pCtx->nco_word = word;
+    pCtx->h_eff = eff;
+    const uint32_t b = resolve_backend(pCtx, pCtx->backend_req);
+    if (!backend_ok(pCtx, b))
+    {
+        pCtx->nco_word = old_word;
+        pCtx->h_eff = old_eff;
+        free(eff);
+        set_err(pCtx, "if_fir_set_nco: backend %u has real-tap arithmetic only (use AUTO, HIP_FFT or HIP_GENERIC)",
+                pCtx->backend_req);
+        return 0;
+    }
+    // kernels in flight still read the old taps and tables
+    hipError_t e = hipSetDevice(pCtx->device);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(pCtx->stream);
+    float *d_new = nullptr;
+    const size_t floats = eff_ctaps(pCtx) ? 2 * (size_t)T : (size_t)T, padded = (floats + 63) / 64 * 64;
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_new, sizeof(float) * padded);
+    if (e == hipSuccess)
+        e = hipMemset(d_new, 0, sizeof(float) * padded);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_new, eff_taps(pCtx), sizeof(float) * floats, hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+        if (d_new)
+            (void)hipFree(d_new);
+        pCtx->nco_word = old_word;
+        pCtx->h_eff = old_eff;
+        free(eff);
+        set_err(pCtx, "if_fir_set_nco: %s", hipGetErrorString(e));
+        return 0;
+    }
+    (void)hipFree(pCtx->d_taps);
+    pCtx->d_taps = d_new;
+    free(old_eff);
+    if (pCtx->d_fft_tables) // H and the row phasors depend on the word: rebuilt on demand
+    {
+        (void)hipFree(pCtx->d_fft_tables);
+        pCtx->d_fft_tables = nullptr;
+    }
+    pCtx->backend = b;
+    if (b == IF_FIR_BACKEND_HIP_FFT && !ensure_fft_tables(pCtx))
+        return 0;
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_get_nco(const if_fir_ctx_t *pCtx, double *pdFreq)
+{
+    if (!pCtx || !pdFreq)
+        return 0;
+    *pdFreq = (double)(int32_t)pCtx->nco_word / 4294967296.0; // the quantised frequency actually applied
+    return 1;
+}
+
 IF_FIR_API uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat)
 {
     if (!pCtx)

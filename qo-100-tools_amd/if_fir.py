@@ -18,6 +18,7 @@ EXPORTS = [
     "if_fir_set_tuning", "if_fir_set_input_format", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
+    "if_fir_set_nco", "if_fir_get_nco",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
 ]
@@ -90,6 +91,10 @@ def lib():
     L.if_fir_debug_stamps.restype = u32
     L.if_fir_device_info.argtypes = [vp, ctypes.c_char_p, u32]
     L.if_fir_device_info.restype = u8
+    L.if_fir_set_nco.argtypes = [vp, ctypes.c_double]
+    L.if_fir_set_nco.restype = u8
+    L.if_fir_get_nco.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+    L.if_fir_get_nco.restype = u8
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.if_fir_mc_owner.argtypes = [u32, u32]
     L.if_fir_mc_owner.restype = u32
@@ -190,6 +195,15 @@ class IfFir:
     def set_input_format(self, fmt):
         self._check(lib().if_fir_set_input_format(self._ctx, int(fmt)))
         self._i16 = (int(fmt) == INPUT_I16)
+
+    def set_nco(self, freq):
+        """if_fir_set_nco(): mix the input with exp(-j 2 pi f a) ahead of the filter (SPEC §3.2); 0 = off."""
+        self._check(lib().if_fir_set_nco(self._ctx, float(freq)))
+
+    def get_nco(self):
+        f = ctypes.c_double(0.0)
+        self._check(lib().if_fir_get_nco(self._ctx, ctypes.byref(f)))
+        return float(f.value)
 
     def set_tuning(self, variant):
         self._check(lib().if_fir_set_tuning(self._ctx, int(variant)))

@@ -59,6 +59,16 @@ def main():
     for dec in (1, 4):
         y = ss.upfirdn(gc.astype(np.complex128), xc, down=dec)[:(n + dec - 1) // dec]
         d["yc_T255_D%d" % dec] = np.ascontiguousarray(y).view(np.float64)
+    # NCO (SPEC §3.2): integer-phase mix by -0.2 cycles/sample (band centre to 0) ahead of the scipy low-pass prototype
+    pw = int(round(0.2 * 2 ** 32)) % 2 ** 32
+    d["nco_phase_word"] = np.array([pw], dtype=np.uint64)
+    a = np.arange(n, dtype=np.uint64)
+    frac = ((a * np.uint64(pw)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 2.0 ** 32
+    xm = xc * np.exp(-2j * np.pi * frac)
+    d["taps_lp_255"] = hl.astype(np.float32)
+    for dec in (1, 4):
+        y = ss.upfirdn(d["taps_lp_255"].astype(np.float64), xm, down=dec)[:(n + dec - 1) // dec]
+        d["ynco_T255_D%d" % dec] = np.ascontiguousarray(y).view(np.float64)
     xr = x[0::2].copy()
     d["xr"] = xr
     d["yr_T127"] = ss.lfilter(d["taps_127"].astype(np.float64), 1.0, xr.astype(np.float64))

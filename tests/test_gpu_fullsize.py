@@ -113,3 +113,57 @@ def test_full_size_fft_backend(fir, oracle, gpu_ok, t, d, log2n):
         y2[2 * m1:] = ytail
         scale = y.abs().max().item()
         assert (y - y2).abs().max().item() <= 1e-6 * scale   # block placement differs, values agree to tolerance
+
+
+def test_full_size_nco_and_index_wrap(fir, oracle, gpu_ok):
+    """NCO at BASELINE size (SPEC §3.2): every output against the generic kernel, windows against the float64 oracle;
+    then the stream is continued past 2^32 samples (17 calls of 2^28) so that the 32-bit phase arithmetic of the
+    kernels wraps: a window of the last call against the oracle at consumed = 16 * 2^28."""
+    import torch
+    torch.cuda.set_device(0)
+    t, d, n = 255, 4, 1 << 28
+    taps = fir.bpf_design(t, 0.0, 0.06)
+    f_nco = 0.1871
+    pw = oracle.nco_phase_word(f_nco)
+    with fir.IfFir(taps, d, 0) as f:
+        f.set_nco(f_nco)
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+        m = f.out_count(n)
+        y = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        f.synth_device(x.data_ptr(), 0, n, 3)
+
+        def window_check(start, consumed, w=8192):
+            lo = max(0, start - (t - 1))
+            xs = x[2 * lo:2 * (start + w)].cpu().numpy()
+            if consumed == 0:
+                hist = np.zeros(2 * (t - 1), dtype=np.float32)
+                hist[2 * (t - 1 - (start - lo)):] = xs[:2 * (start - lo)]
+            else:   # the call continues a stream of identical buffers: the history is the tail of x
+                assert start == 0
+                hist = x[2 * (n - (t - 1)):].cpu().numpy()
+            ref = oracle.fir_nco_f64(taps, xs[2 * (start - lo):], d, pw, hist=hist, consumed=consumed + start)
+            first_out = (start + d - 1) // d
+            got = y[2 * first_out:2 * first_out + ref.size].cpu().numpy()
+            l2, mx = oracle.err_metrics(got, ref)
+            assert l2 <= 1e-6 and mx <= 1e-6, (start, consumed, l2, mx)
+
+        assert f.process_device(x.data_ptr(), y.data_ptr(), n) == m
+        f.synchronize()
+        for start in (0, 3840 * 5 - 64, (n // 3) & ~3, n - 8192):
+            window_check(start, 0)
+        f.reset()
+        f.set_backend(fir.BACKEND_HIP_GENERIC)
+        yg = torch.empty_like(y)
+        f.process_device(x.data_ptr(), yg.data_ptr(), n)
+        f.synchronize()
+        scale = yg.abs().max().item()
+        assert scale > 0.05 and (y - yg).abs().max().item() <= 2e-6 * scale
+        del yg
+        f.set_backend(fir.BACKEND_HIP_FFT)
+        f.reset()
+        for _ in range(17):
+            f.process_device(x.data_ptr(), y.data_ptr(), n)
+        f.synchronize()
+        window_check(0, 16 * n)          # absolute indices 2^32 .. 2^32 + 8191

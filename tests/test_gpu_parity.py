@@ -482,3 +482,86 @@ def test_multi_channel_bootstrap_id(fir, gpu_ok):
     more than the one GPU of this box; their rank/peer bookkeeping is the same c mod world rule the gloo tests cover)."""
     a, b = fir.mc_unique_id(), fir.mc_unique_id()
     assert len(a) == fir.MC_ID_BYTES and any(a) and a != b
+
+
+@pytest.mark.parametrize("t,d,backend", [(255, 4, "fft"), (255, 1, "fft"), (1023, 4, "fft"), (127, 1, "fft"),
+                                         (31, 3, "generic"), (255, 4, "generic")])
+def test_nco_fused_into_the_filter(fir, oracle, t, d, backend):
+    """SPEC §3.2: NCO mix ahead of the filter = complex taps + output rotation inside the kernels.
+    Against the float64 oracle that mixes every input sample by the definition; one call and ragged pieces (the phase
+    follows the absolute sample index, the history holds unmixed samples)."""
+    rng = np.random.default_rng(1000 + t + d)
+    taps = fir.bpf_design(t, 0.0, 0.06) if t >= 3 else np.array([1.0], np.float32)     # low-pass prototype
+    n = 60_011
+    x = np.concatenate([oracle.synth_iq(n // 2, 17), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
+    f = 0.2003
+    pw = oracle.nco_phase_word(f)
+    ref = oracle.fir_nco_f64(taps, x, d, pw)
+    with fir.IfFir(taps, d, n) as flt:
+        flt.set_backend(fir.BACKEND_HIP_FFT if backend == "fft" else fir.BACKEND_HIP_GENERIC)
+        flt.set_nco(f)
+        assert abs(flt.get_nco() - pw / 2.0 ** 32) < 1e-15 and abs(flt.get_nco() - f) <= 2.0 ** -33
+        y = flt.process(x)
+        l2, mx = oracle.err_metrics(y, ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        flt.reset()
+        cuts = [0, 1, 2, 7, 1021, 3841, 3840 * 2 + 6, 20_001, 40_003, n]
+        parts = [flt.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        # negative frequency, then off again: the plain path comes back bit for bit
+        flt.reset()
+        flt.set_nco(-0.31)
+        l2, mx = oracle.err_metrics(flt.process(x), oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(-0.31)))
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        flt.reset()
+        flt.set_nco(0.0)
+        y0 = flt.process(x)
+    with fir.IfFir(taps, d, n) as flt:
+        flt.set_backend(fir.BACKEND_HIP_FFT if backend == "fft" else fir.BACKEND_HIP_GENERIC)
+        assert np.array_equal(flt.process(x), y0)
+
+
+def test_nco_golden_int16_complex_taps_and_refusals(fir, oracle):
+    gold = np.load(GOLD)
+    pw = int(gold["nco_phase_word"][0])
+    h, x = gold["taps_lp_255"], gold["x"]
+    for d in (1, 4):
+        with fir.IfFir(h, d, 4096) as f:
+            f.set_nco(0.2)
+            assert f.get_backend() == fir.BACKEND_HIP_FFT and round(f.get_nco() * 2 ** 32) == pw
+            l2, mx = oracle.err_metrics(f.process(x), gold["ynco_T255_D%d" % d])     # numpy/scipy-made fixture
+            assert l2 <= TOL and mx <= TOL, (d, l2, mx)
+    # int16 input + NCO (both halves of f-1 together), overlap-save and generic
+    n = 50_003
+    xi = np.clip(np.round(oracle.synth_iq(n, 19) * 16384.0), -32768, 32767).astype(np.int16)
+    xf = xi.astype(np.float32) * np.float32(2.0 ** -15)
+    ref = oracle.fir_nco_f64(h, xf, 4, oracle.nco_phase_word(-0.123))
+    with fir.IfFir(h, 4, n) as f:
+        f.set_input_format(fir.INPUT_I16)
+        f.set_nco(-0.123)
+        for b in (fir.BACKEND_HIP_FFT, fir.BACKEND_HIP_GENERIC):
+            f.set_backend(b)
+            f.reset()
+            parts = [f.process(xi[2 * a:2 * b2]) for a, b2 in ((0, 20_001), (20_001, n))]
+            l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
+            assert l2 <= TOL and mx <= TOL, (b, l2, mx)
+    # complex taps + NCO: the taps are rotated as well
+    g = fir.bpf_design_complex(255, 0.1, 0.08)
+    ref = oracle.fir_nco_f64(g, x, 4, oracle.nco_phase_word(0.05), complex_taps=True)
+    with fir.IfFir(g, 4, 4096, complex_taps=True) as f:
+        f.set_nco(0.05)
+        l2, mx = oracle.err_metrics(f.process(x), ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+    # kernels with real-tap arithmetic refuse; the context keeps working without NCO
+    with fir.IfFir(fir.bpf_design(255), 4, 4096, backend=fir.BACKEND_HIP_DIRECT) as f:
+        with pytest.raises(fir.IfFirError, match="real-tap"):
+            f.set_nco(0.1)
+        assert f.get_nco() == 0.0
+        assert np.array_equal(f.process(x), oracle.fir_f32fma(fir.bpf_design(255), x, 4, **SEG))
+        with pytest.raises(fir.IfFirError):
+            f.set_nco(0.75)                       # out of range
+    with fir.IfFir(h, 4, 4096) as f:
+        f.set_nco(0.1)
+        with pytest.raises(fir.IfFirError):
+            f.set_backend(fir.BACKEND_HIP_DIRECT)  # and the other way round

@@ -196,3 +196,33 @@ def test_complex_taps_oracle_matches_golden(oracle, gold):
         tone = np.exp(2j * np.pi * f * n).astype(np.complex64)
         y = oracle.fir_ctaps_f64(g, tone, 1).view(np.complex128)[300:]
         assert abs(np.mean(np.abs(y)) - expect) < 2e-4
+
+
+def test_nco_oracle_matches_golden_and_identity(oracle, gold):
+    """SPEC §3.2: the NCO oracle (mix by the definition, then filter) against the numpy/scipy-made fixture; the
+    complex-taps identity the kernels use (g[k] = h[k] e^{+j theta k}, output rotated by e^{-j theta a}); phase
+    continuity over a cut; frequency quantisation."""
+    pw = int(gold["nco_phase_word"][0])
+    assert pw == oracle.nco_phase_word(0.2) == 858993459
+    assert oracle.nco_phase_word(-0.25) == 3 << 30 and oracle.nco_phase_word(0.0) == 0
+    h = gold["taps_lp_255"]
+    x = gold["x"]
+    n = x.size // 2
+    for d in (1, 4):
+        y = oracle.fir_nco_f64(h, x, d, pw)
+        assert np.max(np.abs(y - gold["ynco_T255_D%d" % d])) <= 4e-15
+        # identity, in float64 throughout
+        theta = 2.0 * np.pi * pw / 2.0 ** 32
+        g = h.astype(np.float64) * np.exp(1j * theta * np.arange(h.size))
+        full = np.convolve(x.astype(np.float64).view(np.complex128), g)[:n]
+        a = np.arange(n, dtype=np.uint64)
+        rot = np.exp(-2j * np.pi * (((a * np.uint64(pw)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 2.0 ** 32))
+        assert np.max(np.abs((full * rot)[::d] - y.view(np.complex128))) <= 1e-13
+        # a cut in the stream: history holds unmixed samples, the phase continues from the absolute index
+        cut = 1501
+        y1 = oracle.fir_nco_f64(h, x[:2 * cut], d, pw)
+        hist = oracle.update_history(h.size, np.zeros(2 * (h.size - 1), np.float32), x[:2 * cut])
+        y2 = oracle.fir_nco_f64(h, x[2 * cut:], d, pw, hist=hist, consumed=cut)
+        assert np.array_equal(np.concatenate([y1, y2]), y)
+    # phase word 0 = no NCO
+    assert np.array_equal(oracle.fir_nco_f64(h, x, 4, 0), oracle.fir_f64(h, x, 4))
