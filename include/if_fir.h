@@ -139,6 +139,17 @@ uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulW
 /* "gfx950", CU count, etc.: writes a short description of the context's device */
 uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOutBytes);
 
+/* ---- uniform filter bank (BUILD-DEFINED) -----------------------------------------------------------
+ * Channel c = mix-down by pulSlots[c]/16 cycles/sample, the context's real prototype taps, decimation by 4: the result
+ * of ulChannels contexts with if_fir_set_nco(slot/16.0), computed in ONE pass over the input.  The context must have
+ * real taps (<= 1025), decimation 4, float32 input, no NCO, and run on the overlap-save backend; its streaming state
+ * (history, decimation phase, sample index) is shared by all channels.  ulChannels 1..16, slots 0..15 (any subset,
+ * repeats allowed); ppDevOut[c]: 16-byte aligned device buffers of if_fir_out_count() samples each.  Asynchronous on
+ * the context's stream like if_fir_process_device. */
+uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots,
+                                          const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples,
+                                          uint64_t *pullOutSamples);
+
 /* ---- multi-channel front (BUILD-DEFINED, the reference has no filter surface) -------------------
  * One process per GPU.  Channel c is filtered by rank if_fir_mc_owner(c, world) = c mod world with its own taps and
  * its own streaming state.  The channel inputs and outputs live on rank 0's GPU; if_fir_mc_process_device() is called

@@ -330,14 +330,15 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
     fft16<true>(c); // over k0 -> mu0
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16, bool NCO>
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
                                                         int32_t waves_total, int32_t RA, int32_t nA, int32_t RB, int32_t nB,
                                                         unsigned int *queue, unsigned long long *dbg, int32_t diag,
-                                                        uint32_t nco_phi0, uint32_t nco_delta)
+                                                        uint32_t nco_phi0, uint32_t nco_delta, ChanArgs chan)
 {
+    static_assert(!CHAN || (DEC4 && !I16 && !NCO), "the channelizer is a decimate-by-4, float32-input variant");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
@@ -513,7 +514,75 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         // outputs beyond M are dropped by the descriptor's bounds check
         const int64_t obase = blk * LOUT;
         const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
-        if constexpr (DEC4)
+        if constexpr (CHAN)
+        {
+            // ---- uniform filter bank: one forward transform, one decimated inverse per channel ---------
+            // Channel slot s = the prototype moved to s/16 cycles/sample and mixed down: H_s(k2) = H(k2 - s), so with the
+            // merged table of the single-channel path  G_s[m0][q] = W16^(m0 s) * G[m0][(q - s) mod 4]  (DESIGN.md §3.7).
+            // First radix-4 stage of pass 3 once, in place: r[phys(i, m0 + 4 q)] = y[q][m0].
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                cf t[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    t[j] = r[phys(i, j)];
+#pragma unroll
+                for (int m0 = 0; m0 < 4; m0++)
+                    bfly4<false>(t[m0], t[m0 + 4], t[m0 + 8], t[m0 + 12], r[phys(i, m0)], r[phys(i, m0 + 4)],
+                                 r[phys(i, m0 + 8)], r[phys(i, m0 + 12)]);
+            }
+            constexpr int MU0_FIRST = OVL_ROWS / 4;
+            const int nch = (int)chan.count;
+            for (int ch = 0; ch < nch; ch++)
+            {
+                const bool last = (ch == nch - 1); // the y values die with the last channel: refill with the next block
+                const int slot = (int)chan.slot[ch];
+                const cf w1 = {chan.tw[ch][0], chan.tw[ch][1]}, w2 = {chan.tw[ch][2], chan.tw[ch][3]},
+                         w3 = {chan.tw[ch][4], chan.tw[ch][5]};
+                cf z[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                    {
+                        const f2v *g = hp + (i * 16 + ((q - slot) & 3)) * 64 + lane; // + m0 * 256 entries
+                        cf acc = cmul_v<false>(r[phys(i, 4 * q)], g[0]);
+                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 1)], w1), g[256]);
+                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 2)], w2), g[512]);
+                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 3)], w3), g[768]);
+                        z[4 * i + q] = acc;
+                    }
+                    if (last && i < EARLY_GROUPS && next_fast)
+                    {
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16>(r, rw, nsrd, lane, phys(i, j));
+                    }
+                }
+                cf c[16];
+                inverse_dec4(z, c, twd, twe, xb, lane);
+                if (last && next_fast)
+                {
+#pragma unroll
+                    for (int i = EARLY_GROUPS; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16>(r, rw, nsrd, lane, phys(i, j));
+                }
+                // mix-down of the decimated output: exp(-j 2 pi slot a / 16), a = abs0 + n0 + 4 m, m = obase + 64 r + lane
+                // with obase a multiple of 4: a call constant (rot0, host) times a quarter turn per lane
+                const cf r0 = {chan.rot0[ch][0], chan.rot0[ch][1]};
+                const int qt = (slot * lane) & 3;
+                const cf wl = qt == 0 ? r0 : qt == 1 ? (cf){r0.y, -r0.x} : qt == 2 ? (cf){-r0.x, -r0.y} : (cf){-r0.y, r0.x};
+                const srd_t csrd = make_srd(chan.out[ch] + obase, (diag & 2) ? 0 : (M - obase) * 8);
+#pragma unroll
+                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    buf_store(csrd, voff, (mu0 - MU0_FIRST) * 512, cmul_v<false>(c[mu0], wl));
+            }
+        }
+        else if constexpr (DEC4)
         {
             // ---- pass 3, multiply by H/4096, fold the 4 aliases: z(i, k2') = sum_j Y(i, k2' + 4j) ------------------
             cf z[16];
@@ -664,10 +733,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     }
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16, bool NCO>
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN = false>
 static hipError_t launch_fft_t(const LaunchArgs &a)
 {
-    auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO>;
+    auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
     constexpr int LOUT = DEC4 ? L / 4 : L;
     static bool attr_done[16] = {false};
@@ -714,7 +783,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist), a.T, a.N,
                        a.n0, a.M, nblocks, (int32_t)(wgs * FFT_WAVES), (int32_t)RA, (int32_t)nA, (int32_t)RB, (int32_t)nB,
                        (unsigned int *)a.queue,
-                       (unsigned long long *)a.dbg, (int32_t)a.diag, nco_phi0(a), nco_delta(a));
+                       (unsigned long long *)a.dbg, (int32_t)a.diag, nco_phi0(a), nco_delta(a),
+                       a.chan ? *a.chan : ChanArgs{});
     return hipGetLastError();
 }
 
@@ -732,6 +802,13 @@ hipError_t launch_fft(const LaunchArgs &a)
 {
     if (!fft_supported(a.T, a.D) || !a.fft_tables)
         return hipErrorInvalidConfiguration;
+    if (a.chan)
+    {
+        if (a.D != 4 || a.in_i16 || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
+            return hipErrorInvalidConfiguration;
+        return fft_overlap_rows(a.T) == 4 ? launch_fft_t<4, true, false, false, true>(a)
+                                          : launch_fft_t<16, true, false, false, true>(a);
+    }
     const int key = (fft_overlap_rows(a.T) == 4 ? 0 : 8) | (a.D == 4 ? 4 : 0) | (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
     switch (key)
     {

@@ -15,6 +15,17 @@ enum
     BACKEND_FFT = 4
 };
 
+// uniform filter bank on the overlap-save kernel: channel c sits at slot[c]/16 cycles/sample
+constexpr int CHAN_MAX = 16;
+struct ChanArgs
+{
+    uint32_t count;
+    uint32_t slot[CHAN_MAX];
+    float tw[CHAN_MAX][6];   // W16^(m0 slot), m0 = 1..3 (re, im)
+    float rot0[CHAN_MAX][2]; // exp(-j 2 pi slot (abs0 + n0) / 16): mix-down phase at this call's first output
+    float2 *out[CHAN_MAX];   // device, M samples each
+};
+
 struct LaunchArgs
 {
     const void *in;    // device, interleaved float32 I/Q, N samples
@@ -37,6 +48,7 @@ struct LaunchArgs
     void *dbg; // optional diagnostic stamp buffer (8192 x 4 x u64) or nullptr
     uint32_t nco_word; // SPEC §3.2 phase word P (0 = no NCO); taps are then the complex g[k] = h[k] e^{+j theta k}
     uint32_t nco_abs0; // absolute index (mod 2^32) of this call's input sample 0
+    const ChanArgs *chan; // filter-bank launch (overlap-save backend, D = 4): `out` is unused, outputs go to chan->out[]
 };
 
 // output m of a call is rotated by exp(+j*2*pi*phi/2^32), phi = nco_phi0 + m * nco_delta (mod 2^32):

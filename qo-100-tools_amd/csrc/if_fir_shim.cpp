@@ -370,7 +370,8 @@ IF_FIR_API uint64_t if_fir_out_count(const if_fir_ctx_t *pCtx, uint64_t ullSampl
 }
 
 // one launch of filter + history kernels; commit = advance the stream state
-static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n, uint64_t *pout, bool commit)
+static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n, uint64_t *pout, bool commit,
+                          if_fir::ChanArgs *chan = nullptr)
 {
     if (n > (uint64_t)1 << 40)
     {
@@ -413,6 +414,17 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     const bool fft_var = ctx->backend == IF_FIR_BACKEND_HIP_FFT;
     a.diag = (fft_var && ctx->variant >= 1000 && ctx->variant < 2000) ? ctx->variant - 1000 : 0;
     a.grid_limit = (fft_var && ctx->variant > 2000 && ctx->variant < 3000) ? ctx->variant - 2000 : 0;
+    if (chan)
+    {
+        // mix-down phase of every channel at this call's first output: exp(-j 2 pi slot (consumed + n0) / 16)
+        for (uint32_t c = 0; c < chan->count; c++)
+        {
+            const uint32_t e = (uint32_t)((chan->slot[c] * ((ctx->consumed + n0) & 15u)) & 15u);
+            chan->rot0[c][0] = (float)cos(-2.0 * M_PI * (double)e / 16.0);
+            chan->rot0[c][1] = (float)sin(-2.0 * M_PI * (double)e / 16.0);
+        }
+        a.chan = chan;
+    }
     if (ctx->backend == IF_FIR_BACKEND_HIP_FFT)
         HIP_TRY(ctx, if_fir::launch_fft(a));
     else
@@ -441,6 +453,63 @@ IF_FIR_API uint8_t if_fir_process_device(if_fir_ctx_t *pCtx, const void *pDevIn,
     }
     HIP_TRY(pCtx, hipSetDevice(pCtx->device));
     return run_device(pCtx, pDevIn, pDevOut, ullSamples, pullOutSamples, true);
+}
+
+// Uniform filter bank (BUILD-DEFINED): channel c = the context's real prototype taps applied after a
+// mix-down by pulSlots[c]/16 cycles/sample, decimated by 4 -- the same result as ulChannels contexts with
+// if_fir_set_nco(slot/16), from ONE pass over the input (one forward transform per block, one small inverse per channel).
+IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots,
+                                                     const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples,
+                                                     uint64_t *pullOutSamples)
+{
+    if (!pCtx)
+        return 0;
+    if (pullOutSamples)
+        *pullOutSamples = 0;
+    if (ulChannels < 1 || ulChannels > (uint32_t)if_fir::CHAN_MAX || !pulSlots || !ppDevOut)
+    {
+        set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot and output arrays", if_fir::CHAN_MAX);
+        return 0;
+    }
+    if (pCtx->D != 4 || pCtx->ctaps || pCtx->nco_word || pCtx->in_i16 || !if_fir::fft_supported(pCtx->T, pCtx->D))
+    {
+        set_err(pCtx, "if_fir_channelizer_process_device: needs real taps (<= 1025), decimation 4, float32 input, no NCO");
+        return 0;
+    }
+    if (pCtx->backend != IF_FIR_BACKEND_HIP_FFT)
+    {
+        set_err(pCtx, "if_fir_channelizer_process_device: the filter bank runs on the overlap-save backend only "
+                      "(context is forced to backend %u)", pCtx->backend);
+        return 0;
+    }
+    if_fir::ChanArgs chan{};
+    chan.count = ulChannels;
+    for (uint32_t c = 0; c < ulChannels; c++)
+    {
+        if (pulSlots[c] > 15 || (ullSamples && !ppDevOut[c]) || ((uintptr_t)ppDevOut[c] & 15))
+        {
+            set_err(pCtx, "if_fir_channelizer_process_device: channel %u: slot must be 0..15 and the output a 16-byte "
+                          "aligned device pointer", c);
+            return 0;
+        }
+        chan.slot[c] = pulSlots[c];
+        chan.out[c] = (float2 *)ppDevOut[c];
+        for (int m0 = 1; m0 < 4; m0++)
+        {
+            const double a = -2.0 * M_PI * (double)((m0 * pulSlots[c]) & 15u) / 16.0; // W16^(m0 slot)
+            chan.tw[c][2 * (m0 - 1) + 0] = (float)cos(a);
+            chan.tw[c][2 * (m0 - 1) + 1] = (float)sin(a);
+        }
+    }
+    if (ullSamples && !pDevIn)
+    {
+        set_err(pCtx, "if_fir_channelizer_process_device: NULL input");
+        return 0;
+    }
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    if (!ensure_fft_tables(pCtx))
+        return 0;
+    return run_device(pCtx, pDevIn, ppDevOut[0], ullSamples, pullOutSamples, true, &chan);
 }
 
 IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float *pfIQOut, uint64_t ullSamples,

@@ -18,7 +18,7 @@ EXPORTS = [
     "if_fir_set_tuning", "if_fir_set_input_format", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
-    "if_fir_set_nco", "if_fir_get_nco",
+    "if_fir_set_nco", "if_fir_get_nco", "if_fir_channelizer_process_device",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
 ]
@@ -95,6 +95,9 @@ def lib():
     L.if_fir_set_nco.restype = u8
     L.if_fir_get_nco.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     L.if_fir_get_nco.restype = u8
+    L.if_fir_channelizer_process_device.argtypes = [vp, u32, ctypes.POINTER(u32), vp, ctypes.POINTER(vp), u64,
+                                                    ctypes.POINTER(u64)]
+    L.if_fir_channelizer_process_device.restype = u8
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.if_fir_mc_owner.argtypes = [u32, u32]
     L.if_fir_mc_owner.restype = u32
@@ -204,6 +207,16 @@ class IfFir:
         f = ctypes.c_double(0.0)
         self._check(lib().if_fir_get_nco(self._ctx, ctypes.byref(f)))
         return float(f.value)
+
+    def channelizer_process_device(self, slots, dev_in, dev_outs, samples):
+        """if_fir_channelizer_process_device(): uniform filter bank, channel c mixed down by slots[c]/16."""
+        k = len(slots)
+        sl = (ctypes.c_uint32 * k)(*[int(v) for v in slots])
+        po = (ctypes.c_void_p * k)(*[ctypes.c_void_p(int(p)) for p in dev_outs])
+        m = ctypes.c_uint64(0)
+        self._check(lib().if_fir_channelizer_process_device(self._ctx, k, sl, ctypes.c_void_p(int(dev_in)), po,
+                                                            int(samples), ctypes.byref(m)))
+        return int(m.value)
 
     def set_tuning(self, variant):
         self._check(lib().if_fir_set_tuning(self._ctx, int(variant)))

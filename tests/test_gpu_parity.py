@@ -565,3 +565,50 @@ def test_nco_golden_int16_complex_taps_and_refusals(fir, oracle):
         f.set_nco(0.1)
         with pytest.raises(fir.IfFirError):
             f.set_backend(fir.BACKEND_HIP_DIRECT)  # and the other way round
+
+
+@pytest.mark.parametrize("t", [255, 1023, 63])
+def test_uniform_filter_bank(fir, oracle, torch_cuda, t):
+    """if_fir_channelizer_process_device = the channels' NCO + prototype + decimate-by-4 results from one
+    pass over the input.  Every channel against the float64 oracle (NCO phase word slot * 2^28), in ragged pieces (odd
+    cuts: every decimation phase and every sample-index residue mod 16 at a call boundary), on the normal grid and
+    through the run queue of a one-workgroup launch."""
+    torch = torch_cuda
+    taps = fir.bpf_design(t, 0.0, 0.03)
+    n = 300_007 if t == 255 else 90_011
+    x = oracle.synth_iq(n, 41)
+    xd = torch.from_numpy(x).cuda()
+    slots = [0, 3, 5, 15, 8, 3, 10]
+    refs = [oracle.fir_nco_f64(taps, x, 4, (s << 28) & 0xFFFFFFFF) for s in slots]
+    cuts = [0, 1, 6, 4103, 40_001, 40_004, n]
+    with fir.IfFir(taps, 4, 0) as f:
+        f.set_backend(fir.BACKEND_HIP_FFT)
+        for tuning in (0, 2001):
+            f.set_tuning(tuning)
+            f.reset()
+            parts = [[] for _ in slots]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                m_exp = oracle.out_count(a, b - a, 4)
+                outs = [torch.full((2 * m_exp + 8,), 3.0, dtype=torch.float32, device="cuda") for _ in slots]
+                piece = xd[2 * a:2 * b].clone()
+                torch.cuda.synchronize()
+                assert f.channelizer_process_device(slots, piece.data_ptr(), [o.data_ptr() for o in outs], b - a) == m_exp
+                f.synchronize()
+                for c in range(len(slots)):
+                    o = outs[c].cpu().numpy()
+                    assert np.all(o[2 * m_exp:] == 3.0)
+                    parts[c].append(o[:2 * m_exp])
+            for c, s in enumerate(slots):
+                y = np.concatenate(parts[c])
+                l2, mx = oracle.err_metrics(y, refs[c])
+                assert l2 <= TOL and mx <= TOL, (t, tuning, s, l2, mx)
+            assert np.array_equal(np.concatenate(parts[1]), np.concatenate(parts[5]))      # the same slot twice
+        # refusals: wrong context kinds, bad slots
+        with pytest.raises(fir.IfFirError, match="slot"):
+            f.channelizer_process_device([16], xd.data_ptr(), [xd.data_ptr()], 16)
+        f.set_nco(0.1)
+        with pytest.raises(fir.IfFirError, match="no NCO"):
+            f.channelizer_process_device([1], xd.data_ptr(), [xd.data_ptr()], 16)
+    with fir.IfFir(taps, 1, 0) as f:
+        with pytest.raises(fir.IfFirError, match="decimation 4"):
+            f.channelizer_process_device([1], xd.data_ptr(), [xd.data_ptr()], 16)
