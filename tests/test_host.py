@@ -17,6 +17,14 @@ def test_library_exports_every_declared_symbol(fir):
     lib = fir.lib()
     for name in declared:
         assert hasattr(lib, name), name
+    # include/wb_detect.h lives in the same library
+    import __graft_entry__ as g
+    wb = g.load_pkg().wb_detect
+    header = open(os.path.join(ROOT, "include", "wb_detect.h")).read()
+    declared = set(re.findall(r"\b(wb_detect_[a-z_]+)\s*\(", header))
+    assert declared == set(wb.EXPORTS), declared ^ set(wb.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
 
 
 def test_library_does_not_link_the_oracle_or_torch():
