@@ -612,3 +612,85 @@ def test_uniform_filter_bank(fir, oracle, torch_cuda, t):
     with fir.IfFir(taps, 1, 0) as f:
         with pytest.raises(fir.IfFirError, match="decimation 4"):
             f.channelizer_process_device([1], xd.data_ptr(), [xd.data_ptr()], 16)
+
+
+def test_random_configurations_against_the_oracle(fir, oracle):
+    """Sweep of random (taps, decimation, length, backend, piece cuts, input format, NCO) combinations: every result
+    within SPEC tolerance of the float64 oracle, the bit-exact kernels equal to their order models."""
+    rng = np.random.default_rng(20261003)
+    names = {fir.BACKEND_HIP_DIRECT: "direct", fir.BACKEND_HIP_TAPSPLIT: "tapsplit", fir.BACKEND_HIP_GENERIC: "generic",
+             fir.BACKEND_HIP_FFT: "fft"}
+    done = {k: 0 for k in names.values()}
+    for case in range(60):
+        t = int(rng.choice([1, 2, 3, 5, 16, 31, 32, 33, 63, 64, 65, 127, 128, 255, 256, 257, 258, 511, 777, 1023, 1025,
+                            1026, 2047, 4096]))
+        d = int(rng.choice([1, 1, 2, 3, 4, 4, 5, 8, 16, 64]))
+        n = int(rng.integers(1, 30_000))
+        taps = (rng.standard_normal(t) / np.sqrt(t)).astype(np.float32)
+        x = rng.standard_normal(2 * n).astype(np.float32)
+        nco = float(rng.uniform(-0.5, 0.5)) if rng.random() < 0.3 else 0.0
+        i16 = rng.random() < 0.25
+        if case % 6 == 0:      # the unrolled direct form exists for four (taps, decimation) pairs only: aim at them
+            t, d, nco, i16 = int(rng.choice([127, 255])), int(rng.choice([1, 4])), 0.0, False
+            taps = (rng.standard_normal(t) / np.sqrt(t)).astype(np.float32)
+        if i16:
+            xi = np.clip(np.round(x * 8000.0), -32768, 32767).astype(np.int16)
+            x = xi.astype(np.float32) * np.float32(2.0 ** -15)
+        choices = [fir.BACKEND_HIP_GENERIC]
+        if not nco and not i16:
+            choices.append(fir.BACKEND_HIP_TAPSPLIT)
+            if t in (127, 255) and d in (1, 4):
+                choices.append(fir.BACKEND_HIP_DIRECT)
+        if d in (1, 4) and t <= 1025:
+            choices += [fir.BACKEND_HIP_FFT] * 2
+        b = fir.BACKEND_HIP_DIRECT if case % 6 == 0 else int(rng.choice(choices))
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))]))
+        ref = oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(nco)) if nco else oracle.fir_f64(taps, x, d)
+        with fir.IfFir(taps, d, n) as f:
+            if i16:
+                f.set_input_format(fir.INPUT_I16)
+            if nco:
+                f.set_nco(nco)
+            f.set_backend(b)
+            src = xi if i16 else x
+            y = np.concatenate([f.process(src[2 * a:2 * c]) for a, c in zip(cuts[:-1], cuts[1:])] or [np.zeros(0, np.float32)])
+        assert y.shape == ref.shape, (case, t, d, n, names[b])
+        if ref.size and np.any(ref):
+            l2, mx = oracle.err_metrics(y, ref)
+            assert l2 <= TOL and mx <= TOL, (case, t, d, n, names[b], nco, i16, cuts, l2, mx)
+        if b in (fir.BACKEND_HIP_DIRECT, fir.BACKEND_HIP_GENERIC) and not nco:
+            assert np.array_equal(y, oracle.fir_f32fma(taps, x, d, **SEG)), (case, t, d, n, names[b])
+        done[names[b]] += 1
+    assert all(v >= 3 for v in done.values()), done
+
+
+def test_contexts_on_concurrent_threads(fir, oracle):
+    """include/if_fir.h: distinct contexts may be used from distinct threads.  Four threads, each with its own context
+    and backend, filter their own stream in pieces at the same time (ctypes releases the GIL during the calls)."""
+    import threading
+    n = 400_003
+    jobs = [(255, 4, fir.BACKEND_HIP_FFT), (255, 4, fir.BACKEND_HIP_DIRECT), (1023, 1, fir.BACKEND_HIP_FFT),
+            (63, 3, fir.BACKEND_HIP_TAPSPLIT)]
+    inputs = [oracle.synth_iq(n, 50 + k) for k in range(len(jobs))]
+    results, errors = [None] * len(jobs), []
+
+    def work(k):
+        try:
+            t, d, b = jobs[k]
+            with fir.IfFir(fir.bpf_design(t), d, n, backend=b) as f:
+                for _ in range(3):                                   # repeat: more time for the threads to overlap
+                    f.reset()
+                    cuts = [0, 100_001, 250_000, n]
+                    results[k] = np.concatenate([f.process(inputs[k][2 * a:2 * c]) for a, c in zip(cuts[:-1], cuts[1:])])
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for k, (t, d, b) in enumerate(jobs):
+        l2, mx = oracle.err_metrics(results[k], oracle.fir_f64(fir.bpf_design(t), inputs[k], d))
+        assert l2 <= TOL and mx <= TOL, (k, l2, mx)
