@@ -371,8 +371,8 @@ def main():
                          "kernel_ms_median": round(float(np.median(per_step)), 4),
                          "kernel_ms_min": round(float(np.min(per_step)), 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "HIP events on the launch stream around the timed steps / steps (includes the "
-                                 "history-update kernel and the queue memset)"},
+                         "note": "HIP events on the launch stream around the timed steps / steps (everything a step "
+                                 "launches: one kernel on the overlap-save path)"},
             "valu": {"achieved": round(achieved_tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved_tf / VALU_PEAK_TFLOPS, 4),
                      "note": ("direct-form-EQUIVALENT rate (4*taps/decimation flop per input sample / time); the "

@@ -277,11 +277,11 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
 // (An earlier version issued the atomic a run ahead through inline asm and waited later: the compiler cannot know
 // that the destination VGPR is still in flight and may spill or copy it before the value lands -- it did, once a
 // change made the kernel spill: every wave then stopped after its first run.  Do not bring that back.)
-__device__ __forceinline__ unsigned queue_ticket(unsigned int *queue, int lane)
+__device__ __forceinline__ unsigned queue_ticket(unsigned int *queue, unsigned base, int lane)
 {
     unsigned t = 0;
     if (lane == 0)
-        t = atomicAdd(queue, 1u);
+        t = atomicAdd(queue, 1u) - base; // the counter runs on from launch to launch (no memset): base = tickets so far
     return __builtin_amdgcn_readfirstlane(t);
 }
 
@@ -336,7 +336,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                                                         int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
                                                         int32_t waves_total, int32_t RA, int32_t nA, int32_t RB, int32_t nB,
                                                         unsigned int *queue, unsigned long long *dbg, int32_t diag,
-                                                        uint32_t nco_phi0, uint32_t nco_delta, ChanArgs chan)
+                                                        uint32_t nco_phi0, uint32_t nco_delta, ChanArgs chan,
+                                                        uint32_t ticket_base, void *__restrict__ hist_out)
 {
     static_assert(!CHAN || (DEC4 && !I16 && !NCO), "the channelizer is a decimate-by-4, float32-input variant");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
@@ -357,6 +358,23 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             dst[i] = src[i];
     }
     __syncthreads();
+    // streaming state: the history of the NEXT call = the last T-1 samples of (history || input), written to the other
+    // ping-pong buffer by one wave (everything it reads is read-only in this launch); spares a launch per call
+    if (hist_out && blockIdx.x == 0 && wid == 0)
+    {
+        const int64_t keep = (int64_t)T - 1;
+        for (int64_t i = lane; i < keep; i += 64)
+        {
+            const int64_t gi = N - keep + i, hi = keep + gi;
+            if constexpr (I16)
+            {
+                const int *src = reinterpret_cast<const int *>(in_), *hsrc = reinterpret_cast<const int *>(hist);
+                reinterpret_cast<int *>(hist_out)[i] = gi >= 0 ? src[gi] : (hi >= 0 ? hsrc[hi] : 0);
+            }
+            else
+                reinterpret_cast<f2v *>(hist_out)[i] = gi >= 0 ? in_[gi] : (hi >= 0 ? hist[hi] : (f2v){0.f, 0.f});
+        }
+    }
     const f2v *tw1 = reinterpret_cast<const f2v *>(smem + LDS_TW1);
     const f2v *hp = reinterpret_cast<const f2v *>(smem + LDS_HP);
     const f2v *tw2 = reinterpret_cast<const f2v *>(smem + LDS_TW2);
@@ -504,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         int64_t blk_next = blk + 1;
         if (blk_next >= blk_end)
         {
-            run_range((int64_t)waves_total + (int64_t)queue_ticket(queue, lane), blk_next, blk_end);
+            run_range((int64_t)waves_total + (int64_t)queue_ticket(queue, ticket_base, lane), blk_next, blk_end);
         }
         const int64_t s0n = blk_next * L - OVL + n0;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
@@ -775,17 +793,33 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     int64_t wgs = wgs_max;
     if (wgs * FFT_WAVES > tickets)
         wgs = (tickets + FFT_WAVES - 1) / FFT_WAVES;
-    hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);
-    if (e != hipSuccess)
-        return e;
+    // the ticket counter is not re-zeroed: every launch consumes exactly `tickets` increments (each wave that runs
+    // takes one ticket per run, the last one beyond the end), so the next launch starts from a known base
+    uint32_t base = 0;
+    if (a.queue_base && a.queue_valid && *a.queue_valid)
+        base = *a.queue_base;
+    else
+    {
+        hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (a.queue_base && a.queue_valid)
+    {
+        *a.queue_base = base + (uint32_t)tickets;
+        *a.queue_valid = true;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), FFT_LDS_BYTES, a.stream,
                        reinterpret_cast<const f2v *>(a.in), reinterpret_cast<f2v *>(a.out),
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist), a.T, a.N,
                        a.n0, a.M, nblocks, (int32_t)(wgs * FFT_WAVES), (int32_t)RA, (int32_t)nA, (int32_t)RB, (int32_t)nB,
                        (unsigned int *)a.queue,
                        (unsigned long long *)a.dbg, (int32_t)a.diag, nco_phi0(a), nco_delta(a),
-                       a.chan ? *a.chan : ChanArgs{});
-    return hipGetLastError();
+                       a.chan ? *a.chan : ChanArgs{}, base, a.hist_out);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess && a.queue_valid)
+        *a.queue_valid = false; // nothing ran: the counter did not advance
+    return le;
 }
 
 bool fft_supported(int T, int D)

@@ -48,6 +48,10 @@ struct LaunchArgs
     void *dbg; // optional diagnostic stamp buffer (8192 x 4 x u64) or nullptr
     uint32_t nco_word; // SPEC §3.2 phase word P (0 = no NCO); taps are then the complex g[k] = h[k] e^{+j theta k}
     uint32_t nco_abs0; // absolute index (mod 2^32) of this call's input sample 0
+    void *hist_out;       // device or nullptr: next history buffer (ping-pong) for the overlap-save kernel to write
+                          // itself; nullptr = the caller runs launch_history (all other backends, or no outputs)
+    uint32_t *queue_base; // host: tickets handed out so far from `queue` by overlap-save launches (the counter is not
+    bool *queue_valid;    //       re-zeroed between them); *queue_valid = false after anybody else touched the counter
     const ChanArgs *chan; // filter-bank launch (overlap-save backend, D = 4): `out` is unused, outputs go to chan->out[]
 };
 

@@ -745,6 +745,8 @@ static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
         blocks = (runs + 3) / 4;
         waves = blocks * 4;
     }
+    if (a.queue_valid)
+        *a.queue_valid = false; // the overlap-save launcher keeps a running ticket base on the same counter
     hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream); // run queue: re-zeroed before every launch
     if (e != hipSuccess)
         return e;

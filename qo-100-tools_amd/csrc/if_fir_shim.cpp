@@ -40,7 +40,9 @@ struct if_fir_ctx
     uint32_t nco_word; // SPEC §3.2 phase word (0 = no NCO)
     float *h_eff; // NCO on: effective complex taps g[k] = h[k] e^{+j theta k} (2T floats), else nullptr
     void *d_fft_tables; // overlap-save backend tables (built on first use)
-    void *d_queue; // atomic run queue of the persistent kernel
+    void *d_queue; // atomic run queue of the persistent kernels
+    uint32_t queue_base; // overlap-save launches let the counter run on: tickets handed out so far ...
+    bool queue_valid;    // ... valid while nobody else (direct kernel, memset) touched the counter
     void *d_dbg; // diagnostic wave stamps (if_fir_debug_stamps)
     char info[128];
     mutable char err[256];
@@ -425,12 +427,18 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
         }
         a.chan = chan;
     }
+    a.queue_base = &ctx->queue_base;
+    a.queue_valid = &ctx->queue_valid;
+    // the overlap-save kernel updates the history itself (one launch per call) whenever it is launched at all
+    const bool fused_history = ctx->backend == IF_FIR_BACKEND_HIP_FFT && m > 0 && ctx->T > 1;
+    a.hist_out = fused_history ? ctx->d_hist[ctx->hist_cur ^ 1] : nullptr;
     if (ctx->backend == IF_FIR_BACKEND_HIP_FFT)
         HIP_TRY(ctx, if_fir::launch_fft(a));
     else
         HIP_TRY(ctx, if_fir::launch_fir(a, ctx->variant));
-    HIP_TRY(ctx, if_fir::launch_history(in, ctx->d_hist[ctx->hist_cur], ctx->d_hist[ctx->hist_cur ^ 1], ctx->T,
-                                        (int64_t)n, ctx->in_i16, ctx->stream));
+    if (!fused_history)
+        HIP_TRY(ctx, if_fir::launch_history(in, ctx->d_hist[ctx->hist_cur], ctx->d_hist[ctx->hist_cur ^ 1], ctx->T,
+                                            (int64_t)n, ctx->in_i16, ctx->stream));
     if (commit)
     {
         ctx->hist_cur ^= 1;
