@@ -330,15 +330,17 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
     fft16<true>(c); // over k0 -> mu0
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN>
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN, bool DECN>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
                                                         int32_t waves_total, int32_t RA, int32_t nA, int32_t RB, int32_t nB,
                                                         unsigned int *queue, unsigned long long *dbg, int32_t diag,
                                                         uint32_t nco_phi0, uint32_t nco_delta, ChanArgs chan,
-                                                        uint32_t ticket_base, void *__restrict__ hist_out)
+                                                        uint32_t ticket_base, void *__restrict__ hist_out,
+                                                        int32_t decn, int32_t decn_n0, int64_t decn_m)
 {
+    static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
     static_assert(!CHAN || (DEC4 && !I16 && !NCO), "the channelizer is a decimate-by-4, float32-input variant");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
@@ -710,6 +712,27 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 a_lane = (cf){pa.x, pa.y};
             }
             (void)a_lane;
+            // general decimation (DECN): the block is filtered at full rate; full-rate output n = obase + 64 r + lane is
+            // kept if n - decn_n0 is a non-negative multiple of D, as output (n - decn_n0) / D.  One 64-bit division per
+            // block and lane (row 0); a row then adds 64 r < 4096 to the remainder, divided by D <= 64 with an exact
+            // multiply-shift (ceil(2^18 / D), exact for numerators below 2^12).
+            unsigned drho0 = 0, dmagic = 0;
+            int drel0 = 0;
+            srd_t dsrd = osrd;
+            if constexpr (DECN)
+            {
+                const uint64_t tp = (uint64_t)(obase + lane - decn_n0 + decn); // > 0 because decn_n0 < D
+                const uint64_t qq = tp / (uint32_t)decn;
+                drho0 = (unsigned)(tp - qq * (uint32_t)decn);
+                const int64_t q0 = (int64_t)qq - 1; // floor((n - n0) / D): -1 for the samples ahead of the first output
+                const uint64_t tpb = (uint64_t)(obase - decn_n0 + decn);
+                const int64_t qfirst = (int64_t)(tpb / (uint32_t)decn) - 1; // lane 0's, wave-uniform by construction
+                const int64_t qb = qfirst < 0 ? 0 : qfirst;
+                drel0 = (int)(q0 - qb);
+                dmagic = (262144u + (unsigned)decn - 1u) / (unsigned)decn;
+                dsrd = make_srd(out + qb, (diag & 2) ? 0 : (decn_m - qb) * 8);
+            }
+            (void)drho0; (void)dmagic; (void)drel0; (void)dsrd;
             // ---- last inverse pass, group by group: finish 16 rows, store them, and refill the same registers with
             //      the next block's rows (the loads fly while the remaining groups and the next forward pass compute)
 #pragma unroll
@@ -733,7 +756,16 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     {
                         if constexpr (NCO)
                             t[j] = cmul_v<false>(t[j], cmul_v<false>(a_lane, ncob[row - OVL_ROWS]));
-                        buf_store(osrd, voff, (row - OVL_ROWS) * 512, t[j]);
+                        if constexpr (DECN)
+                        {
+                            const unsigned u = drho0 + 64u * (unsigned)(row - OVL_ROWS);
+                            const unsigned qd = (u * dmagic) >> 18;
+                            const int rel = drel0 + (int)qd;
+                            const bool keep = (u - qd * (unsigned)decn == 0u) && rel >= 0;
+                            buf_store(dsrd, keep ? (unsigned)rel * 8u : 0xffffffffu, 0, t[j]); // out of range = dropped
+                        }
+                        else
+                            buf_store(osrd, voff, (row - OVL_ROWS) * 512, t[j]);
                     }
                 }
                 if (next_fast)
@@ -751,10 +783,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     }
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN = false>
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN = false, bool DECN = false>
 static hipError_t launch_fft_t(const LaunchArgs &a)
 {
-    auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN>;
+    auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
     constexpr int LOUT = DEC4 ? L / 4 : L;
     static bool attr_done[16] = {false};
@@ -773,7 +805,11 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
         cus[dev] = prop.multiProcessorCount;
         attr_done[dev] = true;
     }
-    const int64_t nblocks = (a.M + LOUT - 1) / LOUT;
+    // DECN: the kernel runs at full rate over the N inputs (blocks, run queue, history as for D = 1) and keeps every
+    // D-th output, the first one at full-rate index n0
+    const int64_t m_rate = DECN ? a.N : a.M;
+    const int32_t n0_rate = DECN ? 0 : a.n0;
+    const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
     if (nblocks <= 0)
         return hipSuccess;
     // guided schedule (see the kernel): ~80 % of the blocks in runs of RA, ~15 % in runs of RB, the rest singly.  Runs
@@ -812,19 +848,21 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), FFT_LDS_BYTES, a.stream,
                        reinterpret_cast<const f2v *>(a.in), reinterpret_cast<f2v *>(a.out),
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist), a.T, a.N,
-                       a.n0, a.M, nblocks, (int32_t)(wgs * FFT_WAVES), (int32_t)RA, (int32_t)nA, (int32_t)RB, (int32_t)nB,
+                       n0_rate, m_rate, nblocks, (int32_t)(wgs * FFT_WAVES), (int32_t)RA, (int32_t)nA, (int32_t)RB, (int32_t)nB,
                        (unsigned int *)a.queue,
-                       (unsigned long long *)a.dbg, (int32_t)a.diag, nco_phi0(a), nco_delta(a),
-                       a.chan ? *a.chan : ChanArgs{}, base, a.hist_out);
+                       (unsigned long long *)a.dbg, (int32_t)a.diag,
+                       DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a), DECN ? 0u - a.nco_word : nco_delta(a),
+                       a.chan ? *a.chan : ChanArgs{}, base, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess && a.queue_valid)
         *a.queue_valid = false; // nothing ran: the counter did not advance
     return le;
 }
 
+// D = 1 and D = 4 have their own kernels; any other decimation runs the full-rate kernel with a selecting store
 bool fft_supported(int T, int D)
 {
-    return (D == 1 || D == 4) && T >= 1 && T <= 1025;
+    return D >= 1 && D <= 64 && T >= 1 && T <= 1025;
 }
 
 int fft_overlap_rows(int T)
@@ -842,6 +880,19 @@ hipError_t launch_fft(const LaunchArgs &a)
             return hipErrorInvalidConfiguration;
         return fft_overlap_rows(a.T) == 4 ? launch_fft_t<4, true, false, false, true>(a)
                                           : launch_fft_t<16, true, false, false, true>(a);
+    }
+    if (a.D != 1 && a.D != 4)
+    {
+        const bool small = fft_overlap_rows(a.T) == 4;
+        if (a.in_i16)
+        {
+            if (a.nco_word)
+                return small ? launch_fft_t<4, false, true, true, false, true>(a) : launch_fft_t<16, false, true, true, false, true>(a);
+            return small ? launch_fft_t<4, false, true, false, false, true>(a) : launch_fft_t<16, false, true, false, false, true>(a);
+        }
+        if (a.nco_word)
+            return small ? launch_fft_t<4, false, false, true, false, true>(a) : launch_fft_t<16, false, false, true, false, true>(a);
+        return small ? launch_fft_t<4, false, false, false, false, true>(a) : launch_fft_t<16, false, false, false, false, true>(a);
     }
     const int key = (fft_overlap_rows(a.T) == 4 ? 0 : 8) | (a.D == 4 ? 4 : 0) | (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
     switch (key)

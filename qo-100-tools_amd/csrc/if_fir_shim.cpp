@@ -81,7 +81,12 @@ static uint32_t resolve_backend(const if_fir_ctx *ctx, uint32_t req)
 {
     if (req != IF_FIR_BACKEND_AUTO)
         return req;
-    if (if_fir::fft_supported(ctx->T, ctx->D) && (ctx->T >= 32 || eff_ctaps(ctx) || ctx->in_i16))
+    // D = 1, 4: dedicated overlap-save kernels.  Other decimations run the full-rate kernel and keep every D-th
+    // output, which costs the same whatever D is, while the tap-split kernel gets cheaper with D: cross-over near
+    // 16 taps per decimated sample (0.04 ms x T/D against ~0.7 ms on 2^28 samples)
+    const bool own_kernel = ctx->D == 1 || ctx->D == 4;
+    const bool worth_it = own_kernel ? ctx->T >= 32 : ctx->T >= 16 * ctx->D;
+    if (if_fir::fft_supported(ctx->T, ctx->D) && (worth_it || eff_ctaps(ctx) || ctx->in_i16))
         return IF_FIR_BACKEND_HIP_FFT;
     if (eff_ctaps(ctx) || ctx->in_i16)
         return IF_FIR_BACKEND_HIP_GENERIC;
@@ -117,7 +122,9 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
         set_err(ctx, "overlap-save tables: out of host memory");
         return 0;
     }
-    if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)ctx->D, tab);
+    // NCO row phasors: per kept output for the decimate-by-4 kernel, per full-rate output for all others
+    if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (ctx->D == 4 ? 4u : 1u),
+                             tab);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * if_fir::FFT_TABLE_FLOATS);

@@ -34,10 +34,13 @@ def test_library_loaded_is_in_tree(fir, gpu_ok):
 
 
 def test_auto_backend_policy(fir, gpu_ok):
-    """AUTO = overlap-save where it applies (>= 32 taps, D in {1,4}, <= 1025 taps), else unrolled direct, else tap-split."""
+    """AUTO = overlap-save where it pays (<= 1025 taps; D in {1,4}: >= 32 taps; other D: >= 16 taps per decimated
+    sample), else the unrolled direct form, else tap-split."""
     expect = {(255, 4): fir.BACKEND_HIP_FFT, (255, 1): fir.BACKEND_HIP_FFT, (127, 1): fir.BACKEND_HIP_FFT,
               (1023, 1): fir.BACKEND_HIP_FFT, (1023, 4): fir.BACKEND_HIP_FFT, (31, 1): fir.BACKEND_HIP_TAPSPLIT,
-              (255, 2): fir.BACKEND_HIP_TAPSPLIT, (2047, 1): fir.BACKEND_HIP_TAPSPLIT}
+              (255, 2): fir.BACKEND_HIP_FFT, (1023, 8): fir.BACKEND_HIP_FFT, (257, 16): fir.BACKEND_HIP_FFT,
+              (255, 16): fir.BACKEND_HIP_TAPSPLIT, (63, 8): fir.BACKEND_HIP_TAPSPLIT,
+              (2047, 1): fir.BACKEND_HIP_TAPSPLIT, (2047, 8): fir.BACKEND_HIP_TAPSPLIT}
     for (t, d), b in expect.items():
         with fir.IfFir(fir.bpf_design(t), d, 16) as f:
             assert f.get_backend() == b, (t, d)
@@ -294,8 +297,7 @@ def test_fft_backend_run_queue_on_small_grid(fir, oracle, t, d, i16):
 
 def test_fft_backend_rejects_unsupported(fir):
     with fir.IfFir(fir.bpf_design(255), 3, 1000) as f:
-        with pytest.raises(fir.IfFirError):
-            f.set_backend(fir.BACKEND_HIP_FFT)        # only D = 1 and D = 4 are built
+        f.set_backend(fir.BACKEND_HIP_FFT)            # any decimation (full-rate kernel + selecting store)
     with fir.IfFir(fir.bpf_design(2047), 1, 1000) as f:
         with pytest.raises(fir.IfFirError):
             f.set_backend(fir.BACKEND_HIP_FFT)        # taps beyond the 4096-point block's overlap
@@ -372,8 +374,7 @@ def test_complex_taps(fir, oracle, t, d):
     x = np.concatenate([oracle.synth_iq(n // 2, 12), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
     ref = oracle.fir_ctaps_f64(g, x, d)
     with fir.IfFir(g, d, n, complex_taps=True) as f:
-        expect_fft = d in (1, 4)
-        assert f.get_backend() == (fir.BACKEND_HIP_FFT if expect_fft else fir.BACKEND_HIP_GENERIC)
+        assert f.get_backend() == fir.BACKEND_HIP_FFT       # complex taps: overlap-save for every decimation
         y = f.process(x)
         l2, mx = oracle.err_metrics(y, ref)
         assert l2 <= TOL and mx <= TOL, (l2, mx)
@@ -412,7 +413,7 @@ def test_int16_input_front_end(fir, oracle, t, d):
     ref = oracle.fir_f64(taps, xf, d)
     with fir.IfFir(taps, d, n) as f:
         f.set_input_format(fir.INPUT_I16)
-        assert f.get_backend() == (fir.BACKEND_HIP_FFT if d in (1, 4) else fir.BACKEND_HIP_GENERIC)
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
         y = f.process(xi)
         l2, mx = oracle.err_metrics(y, ref)
         assert l2 <= TOL and mx <= TOL, (l2, mx)
@@ -641,7 +642,7 @@ def test_random_configurations_against_the_oracle(fir, oracle):
             choices.append(fir.BACKEND_HIP_TAPSPLIT)
             if t in (127, 255) and d in (1, 4):
                 choices.append(fir.BACKEND_HIP_DIRECT)
-        if d in (1, 4) and t <= 1025:
+        if t <= 1025:
             choices += [fir.BACKEND_HIP_FFT] * 2
         b = fir.BACKEND_HIP_DIRECT if case % 6 == 0 else int(rng.choice(choices))
         cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))]))
@@ -694,3 +695,43 @@ def test_contexts_on_concurrent_threads(fir, oracle):
     for k, (t, d, b) in enumerate(jobs):
         l2, mx = oracle.err_metrics(results[k], oracle.fir_f64(fir.bpf_design(t), inputs[k], d))
         assert l2 <= TOL and mx <= TOL, (k, l2, mx)
+
+
+@pytest.mark.parametrize("t,d", [(255, 2), (255, 3), (1023, 8), (63, 5), (257, 16), (1025, 64), (255, 7)])
+def test_fft_backend_any_decimation(fir, oracle, t, d):
+    """Decimations other than 1 and 4 on the overlap-save backend: the full-rate kernel keeps every D-th output (one
+    64-bit division per block and lane, an exact multiply-shift per row).  One call, ragged pieces (every decimation
+    phase at a call boundary), the run queue on a one-workgroup grid, NCO and int16 input on top."""
+    rng = np.random.default_rng(7000 + t + d)
+    taps = fir.bpf_design(t)
+    n = 120_011
+    x = np.concatenate([oracle.synth_iq(n // 2, 23), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
+    ref = oracle.fir_f64(taps, x, d)
+    with fir.IfFir(taps, d, n) as f:
+        f.set_backend(fir.BACKEND_HIP_FFT)
+        y = f.process(x)
+        assert y.shape == ref.shape
+        l2, mx = oracle.err_metrics(y, ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        for tuning in (0, 2001):
+            f.set_tuning(tuning)
+            f.reset()
+            cuts = [0, 1, 2, d, d + 1, 3841, 3842 + d, 50_001, 100_003, n]
+            parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+            yp = np.concatenate(parts)
+            assert yp.shape == ref.shape
+            l2, mx = oracle.err_metrics(yp, ref)
+            assert l2 <= TOL and mx <= TOL, (tuning, l2, mx)
+        f.set_tuning(0)
+        f.reset()
+        f.set_nco(0.137)
+        l2, mx = oracle.err_metrics(f.process(x), oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(0.137)))
+        assert l2 <= TOL and mx <= TOL, ("nco", l2, mx)
+    xi = np.clip(np.round(x * 6000.0), -32768, 32767).astype(np.int16)
+    xf = xi.astype(np.float32) * np.float32(2.0 ** -15)
+    with fir.IfFir(taps, d, n) as f:
+        f.set_input_format(fir.INPUT_I16)
+        f.set_backend(fir.BACKEND_HIP_FFT)
+        parts = [f.process(xi[2 * a:2 * b]) for a, b in ((0, 33_333), (33_333, n))]
+        l2, mx = oracle.err_metrics(np.concatenate(parts), oracle.fir_f64(taps, xf, d))
+        assert l2 <= TOL and mx <= TOL, ("i16", l2, mx)
