@@ -149,6 +149,10 @@ def main():
                     help="kernel family (auto = library default: overlap-save FFT where it applies)")
     ap.add_argument("--scatter", action="store_true", help="also time RCCL scatter/gather of channels from rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels", type=int, default=None,
+                    help="fixed TOTAL number of channels, channel c on rank c mod N, each rank filters its channels back "
+                         "to back (BASELINE configs[3]: 8 channels on 8/4/2/1 GPUs; strong scaling).  Default: one "
+                         "channel per GPU (weak scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,8 +199,24 @@ def main():
     m = f.out_count(n)
     x = torch.empty(2 * n, dtype=torch.float32, device=dev)
     y = torch.empty(2 * m, dtype=torch.float32, device=dev)
-    channel = rank                      # weak scaling: one independent transponder channel per GPU
+    total_channels = args.channels if args.channels else world
+    if total_channels < world:
+        raise SystemExit("--channels must be at least the number of GPUs")
+    owned = [c for c in range(total_channels) if c % world == rank]
+    channel = owned[0]                  # default: one independent transponder channel per GPU (weak scaling)
     f.synth_device(x.data_ptr(), 0, n, channel)
+    torch.cuda.synchronize()
+    more = []                           # further channels of this rank (--channels): own context, input and output
+    for c in owned[1:]:
+        if i16 or nco:
+            raise SystemExit("--channels is implemented for the float32, NCO-less workloads")
+        fc = fir.IfFir(taps, decim, 0, device=local_rank, backend=backend_ids[args.backend])
+        if args.variant is not None:
+            fc.set_tuning(args.variant)
+        fc.set_stream(stream.cuda_stream)
+        xc = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        fc.synth_device(xc.data_ptr(), 0, n, c)
+        more.append((fc, xc, torch.empty(2 * m, dtype=torch.float32, device=dev)))
     torch.cuda.synchronize()
     if i16:
         # int16 front-end: quantise the synthetic stream (full scale = 2.0) on the device, filter the int16 buffer
@@ -213,6 +233,8 @@ def main():
     # every step continues the stream (history + phase carried): identical work per step, no reset memset
     def step_stream():
         f.process_device(x.data_ptr(), y.data_ptr(), n)
+        for fc, xc, yc in more:
+            fc.process_device(xc.data_ptr(), yc.data_ptr(), n)
 
     for _ in range(args.warmup):
         step_stream()
@@ -317,9 +339,10 @@ def main():
 
     if rank == 0:
         ms_per_step = wall_max / args.steps * 1e3
-        value = world * n / (wall_max / args.steps) / 1e6
-        bytes_per_launch = algorithmic_bytes_per_sample(decim, in_bytes) * n
-        flops_per_launch = algorithmic_flops_per_sample(taps_n, decim) * n
+        value = total_channels * n / (wall_max / args.steps) / 1e6
+        # per step on rank 0: its channels back to back (one kernel each)
+        bytes_per_launch = algorithmic_bytes_per_sample(decim, in_bytes) * n * len(owned)
+        flops_per_launch = algorithmic_flops_per_sample(taps_n, decim) * n * len(owned)
         achieved_gbs = bytes_per_launch / (dev_ms_max * 1e-3) / 1e9
         achieved_tf = flops_per_launch / (dev_ms_max * 1e-3) / 1e12
         traffic = None
@@ -361,10 +384,10 @@ def main():
             "metric": "complex-IQ MSamples/s through %d-tap FIR" % taps_n,
             "value": round(value, 1), "unit": "MSamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.channels else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "taps": taps_n, "decimation": decim,
-                       "samples_per_channel": n, "channels_per_gpu": 1,
-                       "parallelism": "channel-parallel x%d, no data-path collective" % world,
+                       "samples_per_channel": n, "channels": total_channels, "channels_on_rank0": len(owned),
+                       "parallelism": "channel c on rank c mod %d, no data-path collective" % world,
                        "backend": names[f.get_backend()],
                        "device": f.device_info()},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
