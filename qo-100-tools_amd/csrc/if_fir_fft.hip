@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                                                         int32_t decn, int32_t decn_n0, int64_t decn_m)
 {
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
-    static_assert(!CHAN || (DEC4 && !I16 && !NCO), "the channelizer is a decimate-by-4, float32-input variant");
+    static_assert(!CHAN || (DEC4 && !NCO), "the channelizer is a decimate-by-4 variant");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
@@ -527,7 +527,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             run_range((int64_t)waves_total + (int64_t)queue_ticket(queue, ticket_base, lane), blk_next, blk_end);
         }
         const int64_t s0n = blk_next * L - OVL + n0;
-        const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
+        // (filter bank on int16 input: the raw next block would need 64 more registers next to the 64 held across the
+        //  channel loop; there the block is loaded at the top of the iteration instead -- per block the bank computes
+        //  for tens of microseconds, the exposed load is a few)
+        const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1) && !(CHAN && I16);
         // diag 16: every wave fetches the same (cached) block -> separates HBM effects from the instruction stream's
         const int64_t s0f = (diag & 16) ? (int64_t)(lane & 0) : s0n;
         const srd_t nsrd = make_srd(in + (next_fast ? s0f : 0) * ISZ, next_fast ? (N - s0f) * ISZ : 0);
@@ -876,8 +879,11 @@ hipError_t launch_fft(const LaunchArgs &a)
         return hipErrorInvalidConfiguration;
     if (a.chan)
     {
-        if (a.D != 4 || a.in_i16 || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
+        if (a.D != 4 || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
             return hipErrorInvalidConfiguration;
+        if (a.in_i16)
+            return fft_overlap_rows(a.T) == 4 ? launch_fft_t<4, true, true, false, true>(a)
+                                              : launch_fft_t<16, true, true, false, true>(a);
         return fft_overlap_rows(a.T) == 4 ? launch_fft_t<4, true, false, false, true>(a)
                                           : launch_fft_t<16, true, false, false, true>(a);
     }

@@ -735,3 +735,32 @@ def test_fft_backend_any_decimation(fir, oracle, t, d):
         parts = [f.process(xi[2 * a:2 * b]) for a, b in ((0, 33_333), (33_333, n))]
         l2, mx = oracle.err_metrics(np.concatenate(parts), oracle.fir_f64(taps, xf, d))
         assert l2 <= TOL and mx <= TOL, ("i16", l2, mx)
+
+
+def test_uniform_filter_bank_int16_input(fir, oracle, torch_cuda):
+    """The filter bank straight on an int16 SDR stream (both halves of §8f-1 and §8f-2 together)."""
+    torch = torch_cuda
+    taps = fir.bpf_design(255, 0.0, 0.03)
+    n = 200_003
+    xi = np.clip(np.round(oracle.synth_iq(n, 43) * 12000.0), -32768, 32767).astype(np.int16)
+    xf = xi.astype(np.float32) * np.float32(2.0 ** -15)
+    xd = torch.from_numpy(xi).cuda()
+    slots = [1, 6, 11, 12]
+    refs = [oracle.fir_nco_f64(taps, xf, 4, (s << 28) & 0xFFFFFFFF) for s in slots]
+    cuts = [0, 4, 50_002, n]          # int16 pieces must start on a 16-byte boundary: multiples of 4 samples
+    with fir.IfFir(taps, 4, 0) as f:
+        f.set_input_format(fir.INPUT_I16)
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        parts = [[] for _ in slots]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            m_exp = oracle.out_count(a, b - a, 4)
+            outs = [torch.empty(2 * m_exp + 8, dtype=torch.float32, device="cuda") for _ in slots]
+            piece = xd[2 * a:2 * b].clone()
+            torch.cuda.synchronize()
+            assert f.channelizer_process_device(slots, piece.data_ptr(), [o.data_ptr() for o in outs], b - a) == m_exp
+            f.synchronize()
+            for c in range(len(slots)):
+                parts[c].append(outs[c].cpu().numpy()[:2 * m_exp])
+        for c, s in enumerate(slots):
+            l2, mx = oracle.err_metrics(np.concatenate(parts[c]), refs[c])
+            assert l2 <= TOL and mx <= TOL, (s, l2, mx)
