@@ -350,7 +350,19 @@ IF_FIR_API uint8_t if_fir_set_stream(if_fir_ctx_t *pCtx, void *pStream)
 {
     if (!pCtx)
         return 0;
-    pCtx->stream = pStream ? (hipStream_t)pStream : pCtx->own_stream;
+    hipStream_t next = pStream ? (hipStream_t)pStream : pCtx->own_stream;
+    if (next != pCtx->stream)
+    {
+        // launches of one context share its run queue, history buffers and tables: they must not overlap, so the work
+        // already queued on the old stream is finished before anything goes to the new one
+        HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+        if (hipStreamSynchronize(pCtx->stream) != hipSuccess) // e.g. the caller has destroyed its old stream already
+        {
+            (void)hipGetLastError();
+            HIP_TRY(pCtx, hipDeviceSynchronize());
+        }
+    }
+    pCtx->stream = next;
     return 1;
 }
 
