@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""wb_bench.py — throughput of the batched WB signal detector (wb_detect_frames_device) with the frames resident in HBM,
-and the oracle restatement on one host core beside it.  usage: python tools/wb_bench.py [frames=262144] [bins=918]"""
+"""bench_wb_detect.py — throughput of the batched WB signal detector (wb_detect_frames_device) with the frames resident in HBM,
+and the oracle restatement on one host core beside it.  usage: python tests/bench_wb_detect.py [frames=262144] [bins=918]
+(lives under tests/ because it calls the oracle as a checker and as the one-core CPU figure)"""
 import json
 import os
 import sys
@@ -12,7 +13,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import __graft_entry__ as g  # noqa: E402
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from test_wb_detect import _random_frames  # noqa: E402  (the frame generator of the tests)
 
 

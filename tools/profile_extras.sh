@@ -10,7 +10,7 @@ O=$R/gpurun_out/${TAG}_extras
 mkdir -p $O
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fbank -- python3 $R/tools/fbank_bench.py 8 28 255 > $O/fbank.json 2> $O/fbank.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/wb -- python3 $R/tools/wb_bench.py 262144 918 > $O/wb.json 2> $O/wb.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/wb -- python3 $R/tests/bench_wb_detect.py 262144 918 > $O/wb.json 2> $O/wb.err
 $R/tools/ubench_mem > $O/ubench_mem.txt 2>&1
 $R/tools/ubench_valu > $O/ubench_valu.txt 2>&1 || true
 python3 $R/tools/small_calls.py > $O/small_calls.txt 2>&1
