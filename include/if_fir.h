@@ -46,7 +46,7 @@ enum
     IF_FIR_BACKEND_HIP_DIRECT = 1,  /* register-blocked sample-stationary direct form, taps in SGPRs            */
     IF_FIR_BACKEND_HIP_TAPSPLIT = 2,/* any T, D: taps staged in LDS, split over 4 lanes, partial sums DPP-reduced */
     IF_FIR_BACKEND_HIP_GENERIC = 3, /* any T, D: one output per thread (simple cross-check kernel)                */
-    IF_FIR_BACKEND_HIP_FFT = 4      /* overlap-save, wave-private 4096-point FFT (T ≤ 1025, any D ≤ 64); AUTO's pick */
+    IF_FIR_BACKEND_HIP_FFT = 4      /* overlap-save, wave-private 4096-point FFT (T ≤ 3073, any D ≤ 64); AUTO's pick */
 };
 
 /* input sample formats (if_fir_set_input_format) */
@@ -142,7 +142,7 @@ uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOu
 /* ---- uniform filter bank (BUILD-DEFINED) -----------------------------------------------------------
  * Channel c = mix-down by pulSlots[c]/16 cycles/sample, the context's real prototype taps, decimation by 4: the result
  * of ulChannels contexts with if_fir_set_nco(slot/16.0), computed in ONE pass over the input.  The context must have
- * real taps (<= 1025), decimation 4, no NCO (float32 or int16 input), and run on the overlap-save backend; its streaming state
+ * real taps (<= 3073), decimation 4, no NCO (float32 or int16 input), and run on the overlap-save backend; its streaming state
  * (history, decimation phase, sample index) is shared by all channels.  ulChannels 1..16, slots 0..15 (any subset,
  * repeats allowed); ppDevOut[c]: 16-byte aligned device buffers of if_fir_out_count() samples each.  Asynchronous on
  * the context's stream like if_fir_process_device. */

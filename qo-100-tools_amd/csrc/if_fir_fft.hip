@@ -862,69 +862,65 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     return le;
 }
 
-// D = 1 and D = 4 have their own kernels; any other decimation runs the full-rate kernel with a selecting store
+// D = 1 and D = 4 have their own kernels; any other decimation runs the full-rate kernel with a selecting store.
+// Taps: the first T-1 outputs of a 4096-point block are discarded, in whole 64-sample rows (4, 16, 32 or 48 of the 64):
+// up to 257 taps cost 6 % of the block, 1025 taps 25 %, 2049 taps half, 3073 taps three quarters.
 bool fft_supported(int T, int D)
 {
-    return D >= 1 && D <= 64 && T >= 1 && T <= 1025;
+    return D >= 1 && D <= 64 && T >= 1 && T <= 3073;
 }
 
 int fft_overlap_rows(int T)
 {
-    return (T - 1 <= 256) ? 4 : 16;
+    return (T - 1 <= 256) ? 4 : (T - 1 <= 1024) ? 16 : (T - 1 <= 2048) ? 32 : 48;
+}
+
+template <int ROWS>
+static hipError_t launch_fft_rows(const LaunchArgs &a)
+{
+    if (a.chan)
+    {
+        if (a.D != 4 || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
+            return hipErrorInvalidConfiguration;
+        return a.in_i16 ? launch_fft_t<ROWS, true, true, false, true>(a) : launch_fft_t<ROWS, true, false, false, true>(a);
+    }
+    const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
+    if (a.D == 4)
+        switch (key)
+        {
+        case 0: return launch_fft_t<ROWS, true, false, false>(a);
+        case 1: return launch_fft_t<ROWS, true, false, true>(a);
+        case 2: return launch_fft_t<ROWS, true, true, false>(a);
+        default: return launch_fft_t<ROWS, true, true, true>(a);
+        }
+    if (a.D == 1)
+        switch (key)
+        {
+        case 0: return launch_fft_t<ROWS, false, false, false>(a);
+        case 1: return launch_fft_t<ROWS, false, false, true>(a);
+        case 2: return launch_fft_t<ROWS, false, true, false>(a);
+        default: return launch_fft_t<ROWS, false, true, true>(a);
+        }
+    switch (key) // any other decimation: full-rate kernel + selecting store
+    {
+    case 0: return launch_fft_t<ROWS, false, false, false, false, true>(a);
+    case 1: return launch_fft_t<ROWS, false, false, true, false, true>(a);
+    case 2: return launch_fft_t<ROWS, false, true, false, false, true>(a);
+    default: return launch_fft_t<ROWS, false, true, true, false, true>(a);
+    }
 }
 
 hipError_t launch_fft(const LaunchArgs &a)
 {
     if (!fft_supported(a.T, a.D) || !a.fft_tables)
         return hipErrorInvalidConfiguration;
-    if (a.chan)
+    switch (fft_overlap_rows(a.T))
     {
-        if (a.D != 4 || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
-            return hipErrorInvalidConfiguration;
-        if (a.in_i16)
-            return fft_overlap_rows(a.T) == 4 ? launch_fft_t<4, true, true, false, true>(a)
-                                              : launch_fft_t<16, true, true, false, true>(a);
-        return fft_overlap_rows(a.T) == 4 ? launch_fft_t<4, true, false, false, true>(a)
-                                          : launch_fft_t<16, true, false, false, true>(a);
+    case 4: return launch_fft_rows<4>(a);
+    case 16: return launch_fft_rows<16>(a);
+    case 32: return launch_fft_rows<32>(a);
+    default: return launch_fft_rows<48>(a);
     }
-    if (a.D != 1 && a.D != 4)
-    {
-        const bool small = fft_overlap_rows(a.T) == 4;
-        if (a.in_i16)
-        {
-            if (a.nco_word)
-                return small ? launch_fft_t<4, false, true, true, false, true>(a) : launch_fft_t<16, false, true, true, false, true>(a);
-            return small ? launch_fft_t<4, false, true, false, false, true>(a) : launch_fft_t<16, false, true, false, false, true>(a);
-        }
-        if (a.nco_word)
-            return small ? launch_fft_t<4, false, false, true, false, true>(a) : launch_fft_t<16, false, false, true, false, true>(a);
-        return small ? launch_fft_t<4, false, false, false, false, true>(a) : launch_fft_t<16, false, false, false, false, true>(a);
-    }
-    const int key = (fft_overlap_rows(a.T) == 4 ? 0 : 8) | (a.D == 4 ? 4 : 0) | (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
-    switch (key)
-    {
-#define IF_FIR_FFT_CASE(K_, ROWS_, DEC_, I16_, NCO_) \
-    case K_:                                         \
-        return launch_fft_t<ROWS_, DEC_, I16_, NCO_>(a)
-        IF_FIR_FFT_CASE(0, 4, false, false, false);
-        IF_FIR_FFT_CASE(1, 4, false, false, true);
-        IF_FIR_FFT_CASE(2, 4, false, true, false);
-        IF_FIR_FFT_CASE(3, 4, false, true, true);
-        IF_FIR_FFT_CASE(4, 4, true, false, false);
-        IF_FIR_FFT_CASE(5, 4, true, false, true);
-        IF_FIR_FFT_CASE(6, 4, true, true, false);
-        IF_FIR_FFT_CASE(7, 4, true, true, true);
-        IF_FIR_FFT_CASE(8, 16, false, false, false);
-        IF_FIR_FFT_CASE(9, 16, false, false, true);
-        IF_FIR_FFT_CASE(10, 16, false, true, false);
-        IF_FIR_FFT_CASE(11, 16, false, true, true);
-        IF_FIR_FFT_CASE(12, 16, true, false, false);
-        IF_FIR_FFT_CASE(13, 16, true, false, true);
-        IF_FIR_FFT_CASE(14, 16, true, true, false);
-        IF_FIR_FFT_CASE(15, 16, true, true, true);
-#undef IF_FIR_FFT_CASE
-    }
-    return hipErrorInvalidConfiguration;
 }
 
 // Host side: twiddle and H tables in the kernel's LDS image order (float64 math, rounded once to float32).

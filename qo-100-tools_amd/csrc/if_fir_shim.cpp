@@ -500,7 +500,7 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
     }
     if (pCtx->D != 4 || pCtx->ctaps || pCtx->nco_word || !if_fir::fft_supported(pCtx->T, pCtx->D))
     {
-        set_err(pCtx, "if_fir_channelizer_process_device: needs real taps (<= 1025), decimation 4, no NCO");
+        set_err(pCtx, "if_fir_channelizer_process_device: needs real taps (<= 3073), decimation 4, no NCO");
         return 0;
     }
     if (pCtx->backend != IF_FIR_BACKEND_HIP_FFT)

@@ -40,7 +40,8 @@ def test_auto_backend_policy(fir, gpu_ok):
               (1023, 1): fir.BACKEND_HIP_FFT, (1023, 4): fir.BACKEND_HIP_FFT, (31, 1): fir.BACKEND_HIP_TAPSPLIT,
               (255, 2): fir.BACKEND_HIP_FFT, (1023, 8): fir.BACKEND_HIP_FFT, (257, 16): fir.BACKEND_HIP_FFT,
               (255, 16): fir.BACKEND_HIP_TAPSPLIT, (63, 8): fir.BACKEND_HIP_TAPSPLIT,
-              (2047, 1): fir.BACKEND_HIP_TAPSPLIT, (2047, 8): fir.BACKEND_HIP_TAPSPLIT}
+              (2047, 1): fir.BACKEND_HIP_FFT, (2047, 8): fir.BACKEND_HIP_FFT, (3073, 4): fir.BACKEND_HIP_FFT,
+              (3075, 1): fir.BACKEND_HIP_TAPSPLIT, (4095, 4): fir.BACKEND_HIP_TAPSPLIT}
     for (t, d), b in expect.items():
         with fir.IfFir(fir.bpf_design(t), d, 16) as f:
             assert f.get_backend() == b, (t, d)
@@ -298,9 +299,9 @@ def test_fft_backend_run_queue_on_small_grid(fir, oracle, t, d, i16):
 def test_fft_backend_rejects_unsupported(fir):
     with fir.IfFir(fir.bpf_design(255), 3, 1000) as f:
         f.set_backend(fir.BACKEND_HIP_FFT)            # any decimation (full-rate kernel + selecting store)
-    with fir.IfFir(fir.bpf_design(2047), 1, 1000) as f:
+    with fir.IfFir(fir.bpf_design(3075), 1, 1000) as f:
         with pytest.raises(fir.IfFirError):
-            f.set_backend(fir.BACKEND_HIP_FFT)        # taps beyond the 4096-point block's overlap
+            f.set_backend(fir.BACKEND_HIP_FFT)        # more than 3073 taps: less than a quarter of a block would be new
 
 
 @pytest.mark.parametrize("t", [255, 127, 1023, 257])
@@ -642,7 +643,7 @@ def test_random_configurations_against_the_oracle(fir, oracle):
             choices.append(fir.BACKEND_HIP_TAPSPLIT)
             if t in (127, 255) and d in (1, 4):
                 choices.append(fir.BACKEND_HIP_DIRECT)
-        if t <= 1025:
+        if t <= 3073:
             choices += [fir.BACKEND_HIP_FFT] * 2
         b = fir.BACKEND_HIP_DIRECT if case % 6 == 0 else int(rng.choice(choices))
         cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))]))
@@ -764,3 +765,31 @@ def test_uniform_filter_bank_int16_input(fir, oracle, torch_cuda):
         for c, s in enumerate(slots):
             l2, mx = oracle.err_metrics(np.concatenate(parts[c]), refs[c])
             assert l2 <= TOL and mx <= TOL, (s, l2, mx)
+
+
+@pytest.mark.parametrize("t,d", [(2047, 1), (2047, 4), (2049, 8), (3073, 1), (3071, 4), (1027, 3)])
+def test_fft_backend_long_filters(fir, oracle, t, d):
+    """More than 1025 taps on the overlap-save backend: 32 or 48 of the 64 rows of a block are overlap (half / three
+    quarters of the transform is redundant, still two orders of magnitude ahead of the direct-form kernels).  One call
+    and ragged pieces against the float64 oracle; complex taps; the run queue on one workgroup."""
+    rng = np.random.default_rng(t + d)
+    taps = fir.bpf_design(t)
+    n = 70_001
+    x = np.concatenate([oracle.synth_iq(n // 2, 29), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
+    ref = oracle.fir_f64(taps, x, d)
+    with fir.IfFir(taps, d, n) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        for tuning in (0, 2001):
+            f.set_tuning(tuning)
+            f.reset()
+            l2, mx = oracle.err_metrics(f.process(x), ref)
+            assert l2 <= TOL and mx <= TOL, (tuning, l2, mx)
+        f.reset()
+        cuts = [0, 3, 1000, 1025, 2048, 2049, 5000, 30_001, n]
+        parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+    g = (rng.standard_normal(2 * t) / np.sqrt(t)).astype(np.float32)
+    with fir.IfFir(g, d, n, complex_taps=True) as f:
+        l2, mx = oracle.err_metrics(f.process(x), oracle.fir_ctaps_f64(g, x, d))
+        assert l2 <= TOL and mx <= TOL, ("ctaps", l2, mx)
