@@ -39,7 +39,7 @@ WORKLOADS = {
     "fir255_dec4_nco_2p28": (255, 4, 28, "NCO mix (0.19995 cycles/sample) fused into the 255-tap FIR + decimate-by-4 (SURVEY §8f-1), 2^28 samples"),
     "fir1023_dec8_2p28": (1023, 8, 28, "1023-tap FIR, decimate-by-8 (overlap-save at full rate + selecting store), 2^28 samples"),
     "fir255_dec2_2p28": (255, 2, 28, "255-tap FIR, decimate-by-2 (overlap-save at full rate + selecting store), 2^28 samples"),
-    "fir2047_dec8_2p26": (2047, 8, 26, "2047-tap FIR, decimate-by-8, 2^26 IQ samples (tap-split kernel territory)"),
+    "fir2047_dec8_2p26": (2047, 8, 26, "2047-tap FIR, decimate-by-8, 2^26 IQ samples (32-row overlap, selecting store)"),
     "fir1023_2p28": (1023, 1, 28, "1023-tap complex-IQ FIR, one channel per GPU, 2^28 IQ samples (BASELINE configs[4])"),
 }
 
