@@ -128,6 +128,10 @@ uint8_t if_fir_synth_device(if_fir_ctx_t *pCtx, void *pDevIQ, uint64_t ullFirst,
 uint8_t if_fir_time_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
                            uint32_t ulWarmup, uint32_t ulReps, float *pfMsPerCall);
 /* Device memory helpers so that a pure-C host needs no HIP headers. */
+/* page-locked host memory (hipHostMalloc) for the buffers of if_fir_process: the copies then run at PCIe speed and
+ * overlap the kernels; ordinary (pageable) buffers work too, more slowly */
+uint8_t if_fir_host_alloc(if_fir_ctx_t *pCtx, void **ppHost, uint64_t ullBytes);
+uint8_t if_fir_host_free(if_fir_ctx_t *pCtx, void *pHost);
 uint8_t if_fir_dev_alloc(if_fir_ctx_t *pCtx, void **ppDev, uint64_t ullBytes);
 uint8_t if_fir_dev_free(if_fir_ctx_t *pCtx, void *pDev);
 uint8_t if_fir_dev_upload(if_fir_ctx_t *pCtx, void *pDev, const void *pHost, uint64_t ullBytes);

@@ -35,6 +35,9 @@ struct if_fir_ctx
     uint64_t max_samples;
     void *d_stage_in;
     void *d_stage_out;
+    hipStream_t copy_in, copy_out; // if_fir_process on long inputs: H2D / kernel / D2H pipelined over chunks
+    hipEvent_t *chunk_ev;          // 2 events per chunk (input landed, outputs ready), created on first use
+    uint32_t chunk_ev_count;
     float tone[10];
     float *h_taps; // host copy of the caller's taps (FFT tables are built on demand)
     uint32_t nco_word; // SPEC §3.2 phase word (0 = no NCO)
@@ -282,6 +285,13 @@ IF_FIR_API void if_fir_destroy(if_fir_ctx_t *pCtx)
     for (int i = 0; i < 2; i++)
         if (pCtx->d_hist[i])
             (void)hipFree(pCtx->d_hist[i]);
+    if (pCtx->copy_in)
+        (void)hipStreamDestroy(pCtx->copy_in);
+    if (pCtx->copy_out)
+        (void)hipStreamDestroy(pCtx->copy_out);
+    for (uint32_t i = 0; i < pCtx->chunk_ev_count; i++)
+        (void)hipEventDestroy(pCtx->chunk_ev[i]);
+    free(pCtx->chunk_ev);
     if (pCtx->d_stage_in)
         (void)hipFree(pCtx->d_stage_in);
     if (pCtx->d_stage_out)
@@ -565,16 +575,97 @@ IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float
         HIP_TRY(pCtx, hipMalloc(&pCtx->d_stage_in, 8 * pCtx->max_samples));
         HIP_TRY(pCtx, hipMalloc(&pCtx->d_stage_out, 8 * (pCtx->max_samples / pCtx->D + 1)));
     }
-    HIP_TRY(pCtx, hipMemcpyAsync(pCtx->d_stage_in, pfIQIn, (pCtx->in_i16 ? 4 : 8) * ullSamples, hipMemcpyHostToDevice,
-                                 pCtx->stream));
-    uint64_t m = 0;
-    if (!run_device(pCtx, pCtx->d_stage_in, pCtx->d_stage_out, ullSamples, &m, true))
-        return 0;
-    if (m)
-        HIP_TRY(pCtx, hipMemcpyAsync(pfIQOut, pCtx->d_stage_out, 8 * m, hipMemcpyDeviceToHost, pCtx->stream));
+    const uint64_t isz = pCtx->in_i16 ? 4 : 8;
+    // Long inputs: chunks of ~2^22 samples flow through three streams (copy in, kernels, copy out), so the transfer of
+    // chunk i+1 and the return of chunk i-1 overlap the filtering of chunk i (PCIe is full duplex; with pinned host
+    // buffers, if_fir_host_alloc, the copies run at link speed).  A chunk is a multiple of 4 D samples: its device
+    // pointers stay 16-byte aligned and it produces exactly chunk / D outputs whatever the decimation phase.
+    const uint64_t unit = 4ull * (uint64_t)pCtx->D;
+    uint64_t chunk = (((uint64_t)1 << 22) / unit) * unit;
+    if (chunk < unit)
+        chunk = unit;
+    while (ullSamples / chunk > 255)
+        chunk *= 2;
+    if (ullSamples < 2 * chunk)
+    {
+        HIP_TRY(pCtx, hipMemcpyAsync(pCtx->d_stage_in, pfIQIn, isz * ullSamples, hipMemcpyHostToDevice, pCtx->stream));
+        uint64_t m = 0;
+        if (!run_device(pCtx, pCtx->d_stage_in, pCtx->d_stage_out, ullSamples, &m, true))
+            return 0;
+        if (m)
+            HIP_TRY(pCtx, hipMemcpyAsync(pfIQOut, pCtx->d_stage_out, 8 * m, hipMemcpyDeviceToHost, pCtx->stream));
+        HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+        if (pullOutSamples)
+            *pullOutSamples = m;
+        return 1;
+    }
+    const uint32_t nchunks = (uint32_t)((ullSamples + chunk - 1) / chunk);
+    if (!pCtx->copy_in)
+    {
+        HIP_TRY(pCtx, hipStreamCreateWithFlags(&pCtx->copy_in, hipStreamNonBlocking));
+        HIP_TRY(pCtx, hipStreamCreateWithFlags(&pCtx->copy_out, hipStreamNonBlocking));
+    }
+    if (pCtx->chunk_ev_count < 2 * nchunks)
+    {
+        hipEvent_t *ev = (hipEvent_t *)realloc(pCtx->chunk_ev, sizeof(hipEvent_t) * 2 * nchunks);
+        if (!ev)
+        {
+            set_err(pCtx, "if_fir_process: out of host memory");
+            return 0;
+        }
+        pCtx->chunk_ev = ev;
+        while (pCtx->chunk_ev_count < 2 * nchunks)
+        {
+            HIP_TRY(pCtx, hipEventCreateWithFlags(&pCtx->chunk_ev[pCtx->chunk_ev_count], hipEventDisableTiming));
+            pCtx->chunk_ev_count++;
+        }
+    }
+    // the copy streams must not run ahead of work already queued on the context's stream (earlier calls)
+    HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+    uint64_t done_in = 0, done_out = 0;
+    for (uint32_t c = 0; c < nchunks; c++)
+    {
+        const uint64_t len = (ullSamples - done_in) < chunk ? (ullSamples - done_in) : chunk;
+        char *d_in = (char *)pCtx->d_stage_in + isz * done_in;
+        char *d_out = (char *)pCtx->d_stage_out + 8 * done_out;
+        HIP_TRY(pCtx, hipMemcpyAsync(d_in, (const char *)pfIQIn + isz * done_in, isz * len, hipMemcpyHostToDevice,
+                                     pCtx->copy_in));
+        HIP_TRY(pCtx, hipEventRecord(pCtx->chunk_ev[2 * c], pCtx->copy_in));
+        HIP_TRY(pCtx, hipStreamWaitEvent(pCtx->stream, pCtx->chunk_ev[2 * c], 0));
+        uint64_t m = 0;
+        if (!run_device(pCtx, d_in, d_out, len, &m, true))
+            return 0;
+        HIP_TRY(pCtx, hipEventRecord(pCtx->chunk_ev[2 * c + 1], pCtx->stream));
+        HIP_TRY(pCtx, hipStreamWaitEvent(pCtx->copy_out, pCtx->chunk_ev[2 * c + 1], 0));
+        if (m)
+            HIP_TRY(pCtx, hipMemcpyAsync(pfIQOut + 2 * done_out, d_out, 8 * m, hipMemcpyDeviceToHost, pCtx->copy_out));
+        done_in += len;
+        done_out += m;
+    }
+    HIP_TRY(pCtx, hipStreamSynchronize(pCtx->copy_out));
     HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
     if (pullOutSamples)
-        *pullOutSamples = m;
+        *pullOutSamples = done_out;
+    return 1;
+}
+
+// pinned host memory for if_fir_process without HIP headers on the caller's side
+IF_FIR_API uint8_t if_fir_host_alloc(if_fir_ctx_t *pCtx, void **ppHost, uint64_t ullBytes)
+{
+    if (!pCtx || !ppHost)
+        return 0;
+    *ppHost = nullptr;
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    HIP_TRY(pCtx, hipHostMalloc(ppHost, ullBytes ? ullBytes : 16, hipHostMallocDefault));
+    return 1;
+}
+
+IF_FIR_API uint8_t if_fir_host_free(if_fir_ctx_t *pCtx, void *pHost)
+{
+    if (!pCtx)
+        return 0;
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    HIP_TRY(pCtx, hipHostFree(pHost));
     return 1;
 }
 

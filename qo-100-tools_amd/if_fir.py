@@ -18,7 +18,7 @@ EXPORTS = [
     "if_fir_set_tuning", "if_fir_set_input_format", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
-    "if_fir_set_nco", "if_fir_get_nco", "if_fir_channelizer_process_device",
+    "if_fir_set_nco", "if_fir_get_nco", "if_fir_channelizer_process_device", "if_fir_host_alloc", "if_fir_host_free",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
 ]
@@ -98,6 +98,10 @@ def lib():
     L.if_fir_channelizer_process_device.argtypes = [vp, u32, ctypes.POINTER(u32), vp, ctypes.POINTER(vp), u64,
                                                     ctypes.POINTER(u64)]
     L.if_fir_channelizer_process_device.restype = u8
+    L.if_fir_host_alloc.argtypes = [vp, ctypes.POINTER(vp), u64]
+    L.if_fir_host_alloc.restype = u8
+    L.if_fir_host_free.argtypes = [vp, vp]
+    L.if_fir_host_free.restype = u8
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.if_fir_mc_owner.argtypes = [u32, u32]
     L.if_fir_mc_owner.restype = u32
@@ -207,6 +211,29 @@ class IfFir:
         f = ctypes.c_double(0.0)
         self._check(lib().if_fir_get_nco(self._ctx, ctypes.byref(f)))
         return float(f.value)
+
+    def host_alloc(self, count, dtype=np.float32):
+        """if_fir_host_alloc(): a page-locked numpy array of `count` elements (free it with host_free(array))."""
+        dtype = np.dtype(dtype)
+        p = ctypes.c_void_p(None)
+        self._check(lib().if_fir_host_alloc(self._ctx, ctypes.byref(p), int(count) * dtype.itemsize))
+        buf = (ctypes.c_char * (int(count) * dtype.itemsize)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(count))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        self._check(lib().if_fir_host_free(self._ctx, ctypes.c_void_p(p)))
+
+    def process_into(self, iq, out):
+        """if_fir_process() with caller-provided host arrays (e.g. from host_alloc); returns the output sample count."""
+        n = iq.size // 2
+        m = ctypes.c_uint64(0)
+        self._check(lib().if_fir_process(self._ctx, ctypes.cast(iq.ctypes.data, ctypes.POINTER(ctypes.c_float)),
+                                         _f32p(out), n, ctypes.byref(m)))
+        return int(m.value)
 
     def channelizer_process_device(self, slots, dev_in, dev_outs, samples):
         """if_fir_channelizer_process_device(): uniform filter bank, channel c mixed down by slots[c]/16."""

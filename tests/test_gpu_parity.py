@@ -793,3 +793,50 @@ def test_fft_backend_long_filters(fir, oracle, t, d):
     with fir.IfFir(g, d, n, complex_taps=True) as f:
         l2, mx = oracle.err_metrics(f.process(x), oracle.fir_ctaps_f64(g, x, d))
         assert l2 <= TOL and mx <= TOL, ("ctaps", l2, mx)
+
+
+@pytest.mark.parametrize("d,i16", [(4, False), (3, False), (4, True), (1, False)])
+def test_host_path_pipelined_chunks(fir, oracle, d, i16):
+    """if_fir_process on a long host buffer: the input goes through the device in chunks on three streams (copy in,
+    kernels, copy out).  Same numbers as the chunk-free device path and the oracle (windows), with pageable and with
+    page-locked (if_fir_host_alloc) buffers, for decimations that do and do not divide the chunk grid."""
+    n = 3 * (1 << 22) + 12_347
+    taps = fir.bpf_design(255)
+    x = oracle.synth_iq(n, 61)
+    if i16:
+        src = np.clip(np.round(x * 12000.0), -32768, 32767).astype(np.int16)
+        x = src.astype(np.float32) * np.float32(2.0 ** -15)
+    else:
+        src = x
+    m = oracle.out_count(0, n, d)
+    with fir.IfFir(taps, d, n) as f:
+        if i16:
+            f.set_input_format(fir.INPUT_I16)
+        y_pageable = f.process(src)
+        assert y_pageable.size == 2 * m
+        # windows against the oracle: start, a chunk seam, the end
+        for start in (0, ((1 << 22) // (4 * d)) * 4 * d - 600, n - 5000):
+            start -= start % d
+            w = min(4000, n - start)
+            lo = max(0, start - 254)
+            hist = np.zeros(2 * 254, np.float32)
+            hist[2 * (254 - (start - lo)):] = x[2 * lo:2 * start]
+            ref = oracle.fir_f64(taps, x[2 * start:2 * (start + w)], d, hist, start)
+            got = y_pageable[2 * (start // d):2 * (start // d) + ref.size]
+            l2, mx = oracle.err_metrics(got, ref)
+            assert l2 <= TOL and mx <= TOL, (start, l2, mx)
+        # page-locked buffers: identical result
+        f.reset()
+        xin = f.host_alloc(2 * n, np.int16 if i16 else np.float32)
+        yout = f.host_alloc(2 * m + 4, np.float32)
+        xin[:] = src
+        yout[:] = 7.0
+        assert f.process_into(xin, yout) == m
+        assert np.array_equal(yout[:2 * m], y_pageable) and np.all(yout[2 * m:] == 7.0)
+        f.host_free(xin)
+        f.host_free(yout)
+        # and a second long call continues the stream (history and phase survive the chunking)
+        f.reset()
+        y2 = np.concatenate([f.process(src[:2 * (n // 2 + 1)]), f.process(src[2 * (n // 2 + 1):])])
+        scale = np.max(np.abs(y_pageable))
+        assert y2.shape == y_pageable.shape and np.max(np.abs(y2 - y_pageable)) <= 2e-6 * scale
