@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--backend", default="auto", choices=["auto", "direct", "fft", "generic"],
                     help="kernel family (auto = library default: overlap-save FFT where it applies)")
     ap.add_argument("--scatter", action="store_true", help="also time RCCL scatter/gather of channels from rank 0")
+    ap.add_argument("--scatter-mc", action="store_true",
+                    help="like --scatter through the library's own multi-channel front (if_fir_mc_*, in-library RCCL); "
+                         "reported in \"extra\", never in `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels", type=int, default=None,
                     help="fixed TOTAL number of channels, channel c on rank c mod N, each rank filters its channels back "
@@ -336,6 +339,41 @@ def main():
         extra["scatter_gather"] = {"scatter_s": t_scatter, "filter_s": t_filter, "gather_s": t_all - t_scatter - t_filter,
                                    "end_to_end_msamples_per_s": world * n / t_all / 1e6,
                                    "note": "RCCL grouped send/recv of whole channels from rank 0 over xGMI"}
+
+    if args.scatter_mc and use_dist and not (i16 or nco):
+        # the C front does the same movement itself: bootstrap id over torch.distributed, then one collective call
+        idt = torch.zeros(fir.MC_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(fir.mc_unique_id()), dtype=torch.uint8).to(dev)
+        dist.broadcast(idt, 0)
+        taps_all = np.stack([taps] * world)
+        with fir.IfFirMc(taps_all, decim, n, device=local_rank, rank=rank, world=world,
+                         unique_id=bytes(idt.cpu().numpy().tobytes())) as mc:
+            ins = outs_mc = None
+            if rank == 0:
+                ins = [x] + [torch.empty_like(x) for _ in range(world - 1)]
+                for c in range(1, world):
+                    f.synth_device(ins[c].data_ptr(), 0, n, c)
+                outs_mc = [torch.empty(2 * m, dtype=torch.float32, device=dev) for _ in range(world)]
+                torch.cuda.synchronize()
+            times = []
+            for _ in range(3):
+                mc.reset()
+                dist.barrier()
+                ts = time.perf_counter()
+                mc.process_device([t_.data_ptr() for t_ in ins] if rank == 0 else None,
+                                  [t_.data_ptr() for t_ in outs_mc] if rank == 0 else None, n)
+                dist.barrier()
+                times.append(time.perf_counter() - ts)
+            check = None
+            if rank == 0:
+                f.reset()
+                f.process_device(x.data_ptr(), y.data_ptr(), n)
+                torch.cuda.synchronize()
+                check = bool(torch.equal(y, outs_mc[0]))
+            extra["scatter_gather_mc"] = {"end_to_end_s": min(times), "end_to_end_msamples_per_s": world * n / min(times) / 1e6,
+                                          "channel0_identical_to_single_context": check,
+                                          "note": "if_fir_mc_process_device: grouped RCCL send/recv from rank 0 inside libif_fir.so"}
 
     if rank == 0:
         ms_per_step = wall_max / args.steps * 1e3
