@@ -101,6 +101,7 @@ uint8_t if_fir_get_nco(const if_fir_ctx_t *pCtx, double *pdFreq);
 /* expert knob: pick a tuning variant of the resolved backend's kernel (0 = default).  Also settable
  * with the environment variable IF_FIR_VARIANT read at if_fir_init. */
 uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant);
+/* (calls on a stream that is being captured into a hipGraph are refused: the streaming state advances on the host) */
 /* run on a caller-owned HIP stream (pass a hipStream_t as void*; NULL = the context's own stream) */
 uint8_t if_fir_set_stream(if_fir_ctx_t *pCtx, void *pStream);
 uint8_t if_fir_synchronize(if_fir_ctx_t *pCtx);

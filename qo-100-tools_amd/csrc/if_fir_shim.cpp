@@ -420,6 +420,15 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
         *pout = m;
     if (n == 0)
         return 1;
+    // the streaming state (sample count, decimation phase, history ping-pong, run-queue base) advances on the host with
+    // every call and is baked into the launch arguments: a captured graph would replay stale state
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &capture) == hipSuccess && capture != hipStreamCaptureStatusNone)
+    {
+        set_err(ctx, "if_fir_process_device: the context's stream is being captured into a hipGraph; calls carry host-side "
+                     "streaming state and cannot be replayed");
+        return 0;
+    }
     if_fir::LaunchArgs a{};
     a.in = in;
     a.out = out;

@@ -840,3 +840,30 @@ def test_host_path_pipelined_chunks(fir, oracle, d, i16):
         y2 = np.concatenate([f.process(src[:2 * (n // 2 + 1)]), f.process(src[2 * (n // 2 + 1):])])
         scale = np.max(np.abs(y_pageable))
         assert y2.shape == y_pageable.shape and np.max(np.abs(y2 - y_pageable)) <= 2e-6 * scale
+
+
+def test_stream_capture_is_refused(fir, oracle, torch_cuda):
+    """A call's launch arguments carry host-side streaming state (sample index, phase, history ping-pong, run-queue
+    base): replaying them from a hipGraph would be wrong, so a capturing stream is refused with a message."""
+    torch = torch_cuda
+    n = 8192
+    x = torch.from_numpy(oracle.synth_iq(n, 2)).cuda()
+    with fir.IfFir(fir.bpf_design(255), 4, n) as f:
+        y = torch.empty(2 * f.out_count(n), dtype=torch.float32, device="cuda")
+        s = torch.cuda.Stream()
+        f.set_stream(s.cuda_stream)
+        f.process_device(x.data_ptr(), y.data_ptr(), n)      # warm: attributes, tables
+        f.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            g.capture_begin()
+            try:
+                with pytest.raises(fir.IfFirError, match="captured"):
+                    f.process_device(x.data_ptr(), y.data_ptr(), n)
+            finally:
+                g.capture_end()
+        f.reset()
+        f.process_device(x.data_ptr(), y.data_ptr(), n)      # the context still works
+        f.synchronize()
+        l2, mx = oracle.err_metrics(y.cpu().numpy(), oracle.fir_f64(fir.bpf_design(255), x.cpu().numpy(), 4))
+        assert l2 <= TOL and mx <= TOL
