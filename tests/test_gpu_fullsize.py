@@ -167,3 +167,44 @@ def test_full_size_nco_and_index_wrap(fir, oracle, gpu_ok):
             f.process_device(x.data_ptr(), y.data_ptr(), n)
         f.synchronize()
         window_check(0, 16 * n)          # absolute indices 2^32 .. 2^32 + 8191
+
+
+def test_beyond_32_bit_offsets(fir, oracle, gpu_ok):
+    """One call of 2^31 + 12 293 samples (17 GB in, 4.3 GB out): sample indices above 2^31 and byte offsets above 2^32
+    in every backend's address arithmetic.  Overlap-save against the direct form on every output, windows against the
+    float64 oracle at the start, around the 2^32-byte line of the input and of the output, and at the very end."""
+    import torch
+    torch.cuda.set_device(0)
+    t, d = 255, 4
+    n = (1 << 31) + 12_293
+    taps = fir.bpf_design(t)
+    with fir.IfFir(taps, d, 0) as f:
+        x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+        m = f.out_count(n)
+        y = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        f.synth_device(x.data_ptr(), 0, n, 5)
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        assert f.process_device(x.data_ptr(), y.data_ptr(), n) == m
+        f.synchronize()
+        w = 4096
+        for start in (0, (1 << 29) - 2048, (1 << 31) - 2048, n - w):      # 2^29 samples = 2^32 input bytes; 2^31 samples = 2^32 output bytes
+            start -= start % d
+            lo = start - (t - 1) if start else 0
+            xs = x[2 * lo:2 * (start + w)].cpu().numpy()
+            assert np.array_equal(xs, oracle.synth_iq(start + w - lo, 5, lo))
+            hist = np.zeros(2 * (t - 1), dtype=np.float32)
+            hist[2 * (t - 1 - (start - lo)):] = xs[:2 * (start - lo)]
+            ref = oracle.fir_f64(taps, xs[2 * (start - lo):], d, hist, start)
+            got = y[2 * (start // d):2 * (start // d) + ref.size].cpu().numpy()
+            l2, mx = oracle.err_metrics(got, ref)
+            assert l2 <= 1e-6 and mx <= 1e-6, (start, l2, mx)
+        f.reset()
+        f.set_backend(fir.BACKEND_HIP_DIRECT)
+        yd = torch.empty_like(y)
+        assert f.process_device(x.data_ptr(), yd.data_ptr(), n) == m
+        f.synchronize()
+        scale = yd.abs().max().item()
+        step = 1 << 28
+        worst = max((y[a:a + step] - yd[a:a + step]).abs().max().item() for a in range(0, y.numel(), step))
+        assert worst <= 2e-6 * scale, worst / scale
