@@ -443,6 +443,27 @@ def main():
                      if f.get_backend() == fir.BACKEND_HIP_FFT else "executed FP32 VALU flops / time"},
             "parity": parity,
         }
+        if world == 1 and not i16:
+            # what this very box's HBM does on plain streaming kernels (context for roofline.frac: the nominal peak is
+            # 8 TB/s, a device-to-device copy of the same buffer reaches about two thirds of it)
+            try:
+                xs = x[:min(x.numel(), 1 << 29)]
+                dst = torch.empty_like(xs)
+                cs0, cs1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(3):
+                    dst.copy_(xs)
+                cs0.record()
+                for _ in range(10):
+                    dst.copy_(xs)
+                cs1.record()
+                torch.cuda.synchronize()
+                copy_ms = cs0.elapsed_time(cs1) / 10
+                extra["hbm_copy_on_this_box"] = {"gbs": round(2 * xs.numel() * 4 / (copy_ms * 1e-3) / 1e9, 1),
+                                                 "frac_of_peak": round(2 * xs.numel() * 4 / (copy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "note": "torch device-to-device copy of %d MiB (read + write bytes / time)" % (xs.numel() * 4 >> 20)}
+                del dst
+            except Exception as e:   # noqa: BLE001 - context only, never fatal
+                extra["hbm_copy_on_this_box"] = {"error": repr(e)}
         if extra:
             line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
