@@ -77,19 +77,16 @@ static void set_err(const if_fir_ctx *ctx, const char *fmt, ...)
 static inline int eff_ctaps(const if_fir_ctx *ctx) { return ctx->ctaps || ctx->nco_word; }
 static inline const float *eff_taps(const if_fir_ctx *ctx) { return ctx->h_eff ? ctx->h_eff : ctx->h_taps; }
 
-// AUTO: the fastest backend that meets SPEC §3 — overlap-save for every (T, D) it covers with at least 32 taps
-// (0.58 ms vs 0.85 ms direct on 255 taps /4, 2^28 samples), else the unrolled direct form, else the tap-split kernel
-// (any T, D); the one-output-per-thread generic kernel stays as an independent cross-check
+// AUTO: the fastest backend that meets SPEC §3.  Measured over (taps, decimation) from 3 taps to 3073 and decimation
+// 1 to 64 (tools/policy_sweep.py, profiles/r01d_policy_sweep.txt) the overlap-save kernel wins wherever it applies --
+// its cost is that of streaming the data, whatever the tap count -- so it is the pick for every T <= 3073; longer
+// filters go to the tap-split kernel.  The unrolled direct form (bit-reproducible order) and the generic kernel
+// (cross-check) are there on request.
 static uint32_t resolve_backend(const if_fir_ctx *ctx, uint32_t req)
 {
     if (req != IF_FIR_BACKEND_AUTO)
         return req;
-    // D = 1, 4: dedicated overlap-save kernels.  Other decimations run the full-rate kernel and keep every D-th
-    // output, which costs the same whatever D is, while the tap-split kernel gets cheaper with D: cross-over near
-    // 16 taps per decimated sample (0.04 ms x T/D against ~0.7 ms on 2^28 samples)
-    const bool own_kernel = ctx->D == 1 || ctx->D == 4;
-    const bool worth_it = own_kernel ? ctx->T >= 32 : ctx->T >= 16 * ctx->D;
-    if (if_fir::fft_supported(ctx->T, ctx->D) && (worth_it || eff_ctaps(ctx) || ctx->in_i16))
+    if (if_fir::fft_supported(ctx->T, ctx->D))
         return IF_FIR_BACKEND_HIP_FFT;
     if (eff_ctaps(ctx) || ctx->in_i16)
         return IF_FIR_BACKEND_HIP_GENERIC;
