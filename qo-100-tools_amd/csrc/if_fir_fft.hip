@@ -839,7 +839,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
         base = *a.queue_base;
     else
     {
-        hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);
+        base = a.queue_seed; // 0 in production; the tests start near 2^32 to cross the wrap of the 32-bit counter
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.queue, (int)base, 4, a.stream);
         if (e != hipSuccess)
             return e;
     }

@@ -52,6 +52,7 @@ struct LaunchArgs
                           // itself; nullptr = the caller runs launch_history (all other backends, or no outputs)
     uint32_t *queue_base; // host: tickets handed out so far from `queue` by overlap-save launches (the counter is not
     bool *queue_valid;    //       re-zeroed between them); *queue_valid = false after anybody else touched the counter
+    uint32_t queue_seed;  // test hook: (re)start the ticket counter and the base at this value (0 = start from zero)
     const ChanArgs *chan; // filter-bank launch (overlap-save backend, D = 4): `out` is unused, outputs go to chan->out[]
 };
 

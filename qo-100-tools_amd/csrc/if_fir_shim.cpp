@@ -464,6 +464,12 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     }
     a.queue_base = &ctx->queue_base;
     a.queue_valid = &ctx->queue_valid;
+    if (fft_var && ctx->variant == 3000) // test hook: restart the run-queue counter 48 tickets below 2^32, once
+    {
+        a.queue_seed = 0xFFFFFFD0u;
+        ctx->queue_valid = false;
+        ctx->variant = 0;
+    }
     // the overlap-save kernel updates the history itself (one launch per call) whenever it is launched at all
     const bool fused_history = ctx->backend == IF_FIR_BACKEND_HIP_FFT && m > 0 && ctx->T > 1;
     a.hist_out = fused_history ? ctx->d_hist[ctx->hist_cur ^ 1] : nullptr;

@@ -867,3 +867,25 @@ def test_stream_capture_is_refused(fir, oracle, torch_cuda):
         f.synchronize()
         l2, mx = oracle.err_metrics(y.cpu().numpy(), oracle.fir_f64(fir.bpf_design(255), x.cpu().numpy(), 4))
         assert l2 <= TOL and mx <= TOL
+
+
+def test_run_queue_counter_wraps(fir, oracle):
+    """The overlap-save launches let the 32-bit ticket counter run on and subtract a host-side base.  Tuning 3000 restarts
+    counter and base 48 tickets below 2^32, so the next launches cross the wrap: same numbers as from a fresh context."""
+    n = 700_001
+    taps = fir.bpf_design(255)
+    x = oracle.synth_iq(n, 71)
+    cuts = [0, 250_000, 500_003, n]
+    with fir.IfFir(taps, 4, n) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        ref = np.concatenate([f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        for grid in (0, 2002):
+            f.reset()
+            f.set_tuning(3000)                     # consumed by the next launch
+            parts = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                parts.append(f.process(x[2 * a:2 * b]))
+                f.set_tuning(grid)                 # a small grid draws many more tickets per launch
+            assert np.array_equal(np.concatenate(parts), ref), grid
+    l2, mx = oracle.err_metrics(ref, oracle.fir_f64(taps, x, 4))
+    assert l2 <= TOL and mx <= TOL
