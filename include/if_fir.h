@@ -141,6 +141,10 @@ uint8_t if_fir_dev_download(if_fir_ctx_t *pCtx, void *pHost, const void *pDev, u
  * persistent direct-form kernel; later calls copy the last launch's stamps (4 x uint64 per wave) and return the
  * number of words written. */
 uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulWords);
+/* host-only diagnostic: the overlap-save kernel's table image (float32, ulOutFloats >= 21120) for these taps; returns the
+ * number of floats written, 0 if the (taps, decimation) pair is not served by that kernel.  Used by the CPU tests. */
+uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
+                                 uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats);
 /* "gfx950", CU count, etc.: writes a short description of the context's device */
 uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOutBytes);
 

@@ -661,6 +661,18 @@ IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float
     return 1;
 }
 
+// Host-only: the overlap-save kernel's LDS table image (twiddles, H or the merged G table, NCO row phasors) for a set
+// of taps, as fft_build_tables() computes it in float64.  Needs no device: the CPU tests check it against numpy.
+IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps,
+                                            uint32_t ulDecimation, uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats)
+{
+    if (!pfTaps || !pfOut || ulOutFloats < (uint32_t)if_fir::FFT_TABLE_FLOATS ||
+        !if_fir::fft_supported((int)ulTaps, (int)ulDecimation))
+        return 0;
+    if_fir::fft_build_tables(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, (int)ulDecimation, ulNcoDelta, pfOut);
+    return (uint32_t)if_fir::FFT_TABLE_FLOATS;
+}
+
 // pinned host memory for if_fir_process without HIP headers on the caller's side
 IF_FIR_API uint8_t if_fir_host_alloc(if_fir_ctx_t *pCtx, void **ppHost, uint64_t ullBytes)
 {

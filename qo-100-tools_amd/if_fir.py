@@ -19,6 +19,7 @@ EXPORTS = [
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
     "if_fir_set_nco", "if_fir_get_nco", "if_fir_channelizer_process_device", "if_fir_host_alloc", "if_fir_host_free",
+    "if_fir_debug_fft_tables",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
 ]
@@ -102,6 +103,8 @@ def lib():
     L.if_fir_host_alloc.restype = u8
     L.if_fir_host_free.argtypes = [vp, vp]
     L.if_fir_host_free.restype = u8
+    L.if_fir_debug_fft_tables.argtypes = [f32p, u32, u32, u32, u32, f32p, u32]
+    L.if_fir_debug_fft_tables.restype = u32
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.if_fir_mc_owner.argtypes = [u32, u32]
     L.if_fir_mc_owner.restype = u32
@@ -326,6 +329,23 @@ class IfFir:
         self._check(lib().if_fir_dev_download(self._ctx, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
                                               host.nbytes))
         return host
+
+
+FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024 + 64)
+
+
+def debug_fft_tables(taps, decimation, complex_taps=False, nco_delta=0):
+    """if_fir_debug_fft_tables(): the overlap-save kernel's table image as complex64 sections (host-only, no GPU)."""
+    taps = np.ascontiguousarray(taps, dtype=np.float32)
+    t = taps.size // 2 if complex_taps else taps.size
+    out = np.zeros(FFT_TABLE_FLOATS, dtype=np.float32)
+    n = lib().if_fir_debug_fft_tables(_f32p(taps), t, 1 if complex_taps else 0, int(decimation), int(nco_delta) & 0xFFFFFFFF,
+                                      _f32p(out), out.size)
+    if n != FFT_TABLE_FLOATS:
+        raise IfFirError("if_fir_debug_fft_tables: (taps=%d, decimation=%d) is not served by the overlap-save kernel" % (t, decimation))
+    c = out.view(np.complex64)
+    return {"tw1": c[0:4096], "hp": c[4096:8192], "tw2": c[8192:8448], "twd": c[8448:9472], "twe": c[9472:10496],
+            "ncob": c[10496:10560]}
 
 
 def mc_owner(channel, world):

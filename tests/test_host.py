@@ -102,3 +102,76 @@ def test_mc_owner_matches_channel_map_and_init_argument_errors(fir):
         fir.IfFirMc(taps, 1, 1000, rank=2, world=2)               # rank out of range
     with pytest.raises(fir.IfFirError, match="unique id"):
         fir.IfFirMc(taps, 1, 1000, rank=0, world=2)               # two ranks without the bootstrap id
+
+
+def _bin_of(i, k2, lane):
+    """frequency bin held by table entry (i, k2, lane) of the overlap-save kernel (csrc/if_fir_fft.hip, fft_build_tables)"""
+    return (4 * (lane // 16) + i) + 16 * (lane % 16) + 256 * k2
+
+
+@pytest.mark.parametrize("t,d,ctaps", [(255, 1, False), (255, 4, False), (1023, 4, False), (63, 3, False), (127, 4, True),
+                                       (2047, 8, False)])
+def test_overlap_save_tables_against_numpy(fir, t, d, ctaps):
+    """Host-side table builder (float64 math in C++, no GPU involved) against an independent numpy derivation: the
+    twiddle tables, H = FFT(taps)/4096 in the kernel's lane order, and for decimate-by-4 the merged table G, which must
+    reproduce 'second radix-4 stage, multiply by H, fold the four aliases' exactly as a linear map."""
+    rng = np.random.default_rng(t + d)
+    if ctaps:
+        h = (rng.standard_normal(t) + 1j * rng.standard_normal(t)) / np.sqrt(t)
+        taps = np.ascontiguousarray(h.astype(np.complex64)).view(np.float32)
+        h = taps.view(np.complex64).astype(np.complex128)
+    else:
+        taps = (rng.standard_normal(t) / np.sqrt(t)).astype(np.float32)
+        h = taps.astype(np.complex128)
+    nco_delta = 0x12345678
+    tab = fir.debug_fft_tables(taps, d, complex_taps=ctaps, nco_delta=nco_delta)
+    lane = np.arange(64)
+    W = lambda n, e: np.exp(-2j * np.pi * (np.asarray(e) % n) / n)   # noqa: E731
+    # twiddles
+    for rho in range(4):
+        for k0 in range(16):
+            assert np.allclose(tab["tw1"][(rho * 16 + k0) * 64:(rho * 16 + k0) * 64 + 64], W(4096, (lane + 64 * rho) * k0), atol=1e-7)
+    for k1 in range(16):
+        assert np.allclose(tab["tw2"][k1 * 16:k1 * 16 + 16], W(256, np.arange(16) * k1), atol=1e-7)
+    r = np.arange(64, dtype=np.uint64)
+    ph = ((r * np.uint64(64) * np.uint64(nco_delta)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 2.0 ** 32
+    assert np.allclose(tab["ncob"], np.exp(2j * np.pi * ph), atol=1e-7)
+    # H in lane order
+    H = np.fft.fft(h, 4096) / 4096.0
+    Hp = np.zeros((4, 16, 64), dtype=np.complex128)
+    for i in range(4):
+        for k2 in range(16):
+            Hp[i, k2] = H[_bin_of(i, k2, lane)]
+    hp = tab["hp"].astype(np.complex128).reshape(4, 16, 64)
+    scale = np.max(np.abs(H))
+    if d != 4:
+        assert np.max(np.abs(hp - Hp)) <= 2e-7 * scale
+        return
+    # merged table: for random pass-2 outputs t[m] (m = time digit of the last 16-point transform),
+    #   sum_p H(q + 4p) * FFT16(t)[q + 4p]  ==  sum_m0 y[q][m0] * G[m0][q],   y[q][m0] = sum_m1 t[m0 + 4 m1] W4^(m1 q)
+    G = hp                                                    # entry (i, 4*m0 + q, lane)
+    tt = rng.standard_normal((4, 16, 64)) + 1j * rng.standard_normal((4, 16, 64))
+    for i in range(4):
+        Y = np.fft.fft(tt[i], axis=0)                         # over the time digit
+        want = np.stack([sum(Hp[i, q + 4 * p] * Y[q + 4 * p] for p in range(4)) for q in range(4)])
+        y = np.zeros((4, 4, 64), dtype=np.complex128)          # y[q][m0]
+        for q in range(4):
+            for m0 in range(4):
+                y[q, m0] = sum(tt[i, m0 + 4 * m1] * W(4, m1 * q) for m1 in range(4))
+        got = np.stack([sum(y[q, m0] * G[i, 4 * m0 + q] for m0 in range(4)) for q in range(4)])
+        assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), (i, np.max(np.abs(got - want)))
+    # filter-bank identity (DESIGN §3.7): a channel at slot s uses G_s[m0][q] = W16^(m0 s) G[m0][(q - s) mod 4],
+    # which must equal the merged table of the prototype shifted up by 256 s bins
+    for s in (1, 6, 11):
+        Hs = np.roll(H, 256 * s)
+        for i in range(4):
+            for m0 in range(4):
+                for q in range(4):
+                    direct = W(16, m0 * q) * sum(Hs[_bin_of(i, q + 4 * p, lane)] * W(4, m0 * p) for p in range(4))
+                    via = W(16, m0 * s) * G[i, 4 * m0 + ((q - s) % 4)]
+                    assert np.max(np.abs(direct - via)) <= 3e-7 * scale, (s, i, m0, q)
+
+
+def test_overlap_save_tables_refuse_unsupported(fir):
+    with pytest.raises(fir.IfFirError):
+        fir.debug_fft_tables(np.ones(3075, np.float32), 1)
