@@ -786,6 +786,33 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     }
 }
 
+// Guided schedule of the run queue (see the kernel): ticket q < nA is a run of RA blocks, the next nB tickets are runs
+// of RB blocks, the rest single blocks: ~80 % of the blocks in long runs (the counter stays far from its ~88 tickets/us
+// limit), small pieces at the end keep the tail short.  `tickets` is also the exact number of counter increments of a
+// launch (every wave that runs takes one ticket per run, the last one beyond the end), which is what lets launches
+// share a running counter.
+void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s)
+{
+    const int64_t waves_max = wgs_max * FFT_WAVES;
+    int64_t RA = nblocks / (waves_max * 4);
+    RA = RA < 1 ? 1 : (RA > 8 ? 8 : RA);
+    const int64_t RB = RA >= 4 ? 2 : 1;
+    int64_t nA = (nblocks * 8 / 10) / RA;
+    if (nA < waves_max && nA * RA < nblocks)
+        nA = (nblocks / RA < waves_max) ? nblocks / RA : waves_max; // every wave starts with a full run when possible
+    int64_t nB = RB > 1 ? (nblocks * 15 / 100) / RB : 0;
+    if (nA * RA + nB * RB > nblocks)
+        nB = (nblocks - nA * RA) / RB;
+    s.RA = RA;
+    s.nA = nA;
+    s.RB = RB;
+    s.nB = nB;
+    s.tickets = nA + nB + (nblocks - nA * RA - nB * RB);
+    s.wgs = wgs_max;
+    if (s.wgs * FFT_WAVES > s.tickets)
+        s.wgs = (s.tickets + FFT_WAVES - 1) / FFT_WAVES;
+}
+
 template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN = false, bool DECN = false>
 static hipError_t launch_fft_t(const LaunchArgs &a)
 {
@@ -815,23 +842,10 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
     if (nblocks <= 0)
         return hipSuccess;
-    // guided schedule (see the kernel): ~80 % of the blocks in runs of RA, ~15 % in runs of RB, the rest singly.  Runs
-    // keep the counter far from saturation (~88 tickets/us); small pieces at the end keep the tail short.
     const int64_t wgs_max = (a.grid_limit > 0 && a.grid_limit < cus[dev]) ? a.grid_limit : cus[dev];
-    const int64_t waves_max = wgs_max * FFT_WAVES;
-    int64_t RA = nblocks / (waves_max * 4);
-    RA = RA < 1 ? 1 : (RA > 8 ? 8 : RA);
-    int64_t RB = RA >= 4 ? 2 : 1;
-    int64_t nA = (nblocks * 8 / 10) / RA;
-    if (nA < waves_max && nA * RA < nblocks)
-        nA = (nblocks / RA < waves_max) ? nblocks / RA : waves_max; // every wave starts with a full run when possible
-    int64_t nB = RB > 1 ? (nblocks * 15 / 100) / RB : 0;
-    if (nA * RA + nB * RB > nblocks)
-        nB = (nblocks - nA * RA) / RB;
-    const int64_t tickets = nA + nB + (nblocks - nA * RA - nB * RB);
-    int64_t wgs = wgs_max;
-    if (wgs * FFT_WAVES > tickets)
-        wgs = (tickets + FFT_WAVES - 1) / FFT_WAVES;
+    FftSchedule sch;
+    fft_schedule(nblocks, wgs_max, sch);
+    const int64_t RA = sch.RA, nA = sch.nA, RB = sch.RB, nB = sch.nB, tickets = sch.tickets, wgs = sch.wgs;
     // the ticket counter is not re-zeroed: every launch consumes exactly `tickets` increments (each wave that runs
     // takes one ticket per run, the last one beyond the end), so the next launch starts from a known base
     uint32_t base = 0;

@@ -77,6 +77,11 @@ hipError_t launch_fir(const LaunchArgs &a, int variant);
 // overlap-save FFT backend (if_fir_fft.hip)
 constexpr int FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024 + 64); // ... + 64 NCO row phasors
 bool fft_supported(int T, int D);
+struct FftSchedule
+{
+    int64_t RA, nA, RB, nB, tickets, wgs;
+};
+void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s); // host-only: run-queue layout of a launch
 hipError_t launch_fft(const LaunchArgs &a);
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, float *tables);
 

@@ -673,6 +673,23 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
 }
 
+// Host-only: the run-queue layout the overlap-save launcher would use for nblocks blocks on at most ulWorkgroups
+// workgroups; pllOut receives RA, nA, RB, nB, tickets, workgroups.  The CPU tests check that the tickets tile the blocks.
+IF_FIR_API uint8_t if_fir_debug_fft_schedule(uint64_t ullBlocks, uint32_t ulWorkgroups, int64_t *pllOut)
+{
+    if (!pllOut || !ullBlocks || !ulWorkgroups)
+        return 0;
+    if_fir::FftSchedule s;
+    if_fir::fft_schedule((int64_t)ullBlocks, (int64_t)ulWorkgroups, s);
+    pllOut[0] = s.RA;
+    pllOut[1] = s.nA;
+    pllOut[2] = s.RB;
+    pllOut[3] = s.nB;
+    pllOut[4] = s.tickets;
+    pllOut[5] = s.wgs;
+    return 1;
+}
+
 // pinned host memory for if_fir_process without HIP headers on the caller's side
 IF_FIR_API uint8_t if_fir_host_alloc(if_fir_ctx_t *pCtx, void **ppHost, uint64_t ullBytes)
 {

@@ -19,7 +19,7 @@ EXPORTS = [
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
     "if_fir_set_nco", "if_fir_get_nco", "if_fir_channelizer_process_device", "if_fir_host_alloc", "if_fir_host_free",
-    "if_fir_debug_fft_tables",
+    "if_fir_debug_fft_tables", "if_fir_debug_fft_schedule",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
 ]
@@ -105,6 +105,8 @@ def lib():
     L.if_fir_host_free.restype = u8
     L.if_fir_debug_fft_tables.argtypes = [f32p, u32, u32, u32, u32, f32p, u32]
     L.if_fir_debug_fft_tables.restype = u32
+    L.if_fir_debug_fft_schedule.argtypes = [u64, u32, ctypes.POINTER(ctypes.c_int64)]
+    L.if_fir_debug_fft_schedule.restype = u8
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.if_fir_mc_owner.argtypes = [u32, u32]
     L.if_fir_mc_owner.restype = u32
@@ -346,6 +348,14 @@ def debug_fft_tables(taps, decimation, complex_taps=False, nco_delta=0):
     c = out.view(np.complex64)
     return {"tw1": c[0:4096], "hp": c[4096:8192], "tw2": c[8192:8448], "twd": c[8448:9472], "twe": c[9472:10496],
             "ncob": c[10496:10560]}
+
+
+def debug_fft_schedule(nblocks, workgroups=256):
+    """if_fir_debug_fft_schedule(): dict(RA, nA, RB, nB, tickets, wgs) of an overlap-save launch (host-only)."""
+    out = (ctypes.c_int64 * 6)()
+    if not lib().if_fir_debug_fft_schedule(int(nblocks), int(workgroups), out):
+        raise IfFirError("if_fir_debug_fft_schedule: bad arguments")
+    return dict(zip(("RA", "nA", "RB", "nB", "tickets", "wgs"), [int(v) for v in out]))
 
 
 def mc_owner(channel, world):

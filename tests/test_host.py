@@ -175,3 +175,37 @@ def test_overlap_save_tables_against_numpy(fir, t, d, ctaps):
 def test_overlap_save_tables_refuse_unsupported(fir):
     with pytest.raises(fir.IfFirError):
         fir.debug_fft_tables(np.ones(3075, np.float32), 1)
+
+
+def test_overlap_save_run_queue_schedule_tiles_the_blocks(fir):
+    """The guided schedule of the overlap-save launcher (host logic): ticket q is the block range the kernel's run_range()
+    derives from (RA, nA, RB, nB); over q = 0 .. tickets-1 the ranges must tile [0, nblocks) exactly once, ticket
+    `tickets` and beyond must be empty (that is how a wave learns it is done, and why a launch consumes exactly
+    `tickets` counter increments), and no more workgroups are launched than there are tickets for their waves."""
+    def run_range(q, s, nblocks):        # mirror of the device lambda in fir_fft_kernel
+        if q < s["nA"]:
+            b0, b1 = q * s["RA"], q * s["RA"] + s["RA"]
+        elif q < s["nA"] + s["nB"]:
+            b0 = s["nA"] * s["RA"] + (q - s["nA"]) * s["RB"]
+            b1 = b0 + s["RB"]
+        else:
+            b0 = s["nA"] * s["RA"] + s["nB"] * s["RB"] + (q - s["nA"] - s["nB"])
+            b1 = b0 + 1
+        return b0, min(b1, nblocks)
+
+    rng = np.random.default_rng(5)
+    sizes = [1, 2, 7, 8, 9, 63, 64, 65, 2047, 2048, 2049, 4369, 8191, 16384, 17477, 69870, 69871, 139810, 1 << 20]
+    sizes += [int(v) for v in rng.integers(1, 300_000, size=40)]
+    for nblocks in sizes:
+        for wgs in (1, 2, 3, 8, 256, 304):
+            s = fir.debug_fft_schedule(nblocks, wgs)
+            assert 1 <= s["RA"] <= 8 and s["RB"] in (1, 2) and s["nA"] >= 0 and s["nB"] >= 0
+            assert 1 <= s["wgs"] <= wgs and (s["wgs"] - 1) * 8 < s["tickets"]
+            nxt = 0
+            for q in range(s["tickets"]):
+                b0, b1 = run_range(q, s, nblocks)
+                assert b0 == nxt and b1 > b0, (nblocks, wgs, q, b0, b1, s)
+                nxt = b1
+            assert nxt == nblocks, (nblocks, wgs, s)
+            for q in (s["tickets"], s["tickets"] + 1, s["tickets"] + 5000):
+                assert run_range(q, s, nblocks)[0] >= nblocks
