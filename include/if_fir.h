@@ -129,6 +129,9 @@ uint8_t if_fir_synth_device(if_fir_ctx_t *pCtx, void *pDevIQ, uint64_t ullFirst,
 uint8_t if_fir_time_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
                            uint32_t ulWarmup, uint32_t ulReps, float *pfMsPerCall);
 /* Device memory helpers so that a pure-C host needs no HIP headers. */
+/* mean(|y|^2) of a device IQ buffer (float32 I,Q), accumulated in float64; synchronous.  The measurement side of a
+ * level-control loop; writing the attenuator register stays with the rack controller's daemon. */
+uint8_t if_fir_power_device(if_fir_ctx_t *pCtx, const void *pDevIQ, uint64_t ullSamples, double *pdMeanPower);
 /* page-locked host memory (hipHostMalloc) for the buffers of if_fir_process: the copies then run at PCIe speed and
  * overlap the kernels; ordinary (pageable) buffers work too, more slowly */
 uint8_t if_fir_host_alloc(if_fir_ctx_t *pCtx, void **ppHost, uint64_t ullBytes);

@@ -87,6 +87,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
 
 hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, int in_i16,
                           hipStream_t stream);
+hipError_t launch_power(const void *iq, uint64_t samples, double *acc, hipStream_t stream); // acc: device double
 hipError_t launch_synth(void *iq, uint64_t first, uint64_t count, uint32_t channel, const float *tone10,
                         hipStream_t stream);
 

@@ -893,6 +893,52 @@ hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, i
     return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// in-band power of an IQ buffer: sum of |y|^2 (what a rack-control loop would feed back into the IF
+// attenuator).  HBM-bound reduction: 16-byte loads, float64 accumulation per lane (2^28 float32 squares overflow
+// float32's 24 bits of exactness), wave reduction by DPP-free shuffles, one float64 atomic per workgroup.
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void power_kernel(const float4 *__restrict__ iq2, uint64_t pairs, const f2 *__restrict__ tail,
+                                                   uint32_t tail_count, double *__restrict__ acc)
+{
+    double s = 0.0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride)
+    {
+        const float4 v = iq2[i]; // two samples
+        s += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < tail_count)
+    {
+        const f2 v = tail[threadIdx.x];
+        s += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicAdd(acc, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+hipError_t launch_power(const void *iq, uint64_t samples, double *acc, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(acc, 0, sizeof(double), stream);
+    if (e != hipSuccess || samples == 0)
+        return e;
+    const uint64_t pairs = samples / 2;
+    uint64_t blocks = (pairs + 255) / 256;
+    if (blocks > 4096)
+        blocks = 4096;
+    if (blocks == 0)
+        blocks = 1;
+    hipLaunchKernelGGL(power_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(iq), pairs,
+                       reinterpret_cast<const f2 *>(iq) + 2 * pairs, (uint32_t)(samples & 1), acc);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(void *iq, uint64_t first, uint64_t count, uint32_t channel, const float *tone10,
                         hipStream_t stream)
 {

@@ -47,6 +47,7 @@ struct if_fir_ctx
     uint32_t queue_base; // overlap-save launches let the counter run on: tickets handed out so far ...
     bool queue_valid;    // ... valid while nobody else (direct kernel, memset) touched the counter
     void *d_dbg; // diagnostic wave stamps (if_fir_debug_stamps)
+    void *d_power; // one float64 accumulator (if_fir_power_device)
     char info[128];
     mutable char err[256];
 };
@@ -295,6 +296,8 @@ IF_FIR_API void if_fir_destroy(if_fir_ctx_t *pCtx)
         (void)hipFree(pCtx->d_stage_out);
     if (pCtx->d_dbg)
         (void)hipFree(pCtx->d_dbg);
+    if (pCtx->d_power)
+        (void)hipFree(pCtx->d_power);
     if (pCtx->d_queue)
         (void)hipFree(pCtx->d_queue);
     if (pCtx->d_fft_tables)
@@ -687,6 +690,32 @@ IF_FIR_API uint8_t if_fir_debug_fft_schedule(uint64_t ullBlocks, uint32_t ulWork
     pllOut[3] = s.nB;
     pllOut[4] = s.tickets;
     pllOut[5] = s.wgs;
+    return 1;
+}
+
+// Mean power of a device IQ buffer, mean(|y|^2): what a control loop feeds back into an attenuator (the
+// reference's rack controller sets the IF attenuation through I2C register 0x20, lib/upconverter.js:176-187; the
+// register write stays with the daemon).  Synchronous (returns the number).
+IF_FIR_API uint8_t if_fir_power_device(if_fir_ctx_t *pCtx, const void *pDevIQ, uint64_t ullSamples, double *pdMeanPower)
+{
+    if (!pCtx || !pdMeanPower)
+        return 0;
+    *pdMeanPower = 0.0;
+    if (ullSamples == 0)
+        return 1;
+    if (!pDevIQ || ((uintptr_t)pDevIQ & 15))
+    {
+        set_err(pCtx, "if_fir_power_device: the buffer must be a 16-byte aligned device pointer");
+        return 0;
+    }
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    if (!pCtx->d_power)
+        HIP_TRY(pCtx, hipMalloc(&pCtx->d_power, sizeof(double)));
+    HIP_TRY(pCtx, if_fir::launch_power(pDevIQ, ullSamples, (double *)pCtx->d_power, pCtx->stream));
+    double sum = 0.0;
+    HIP_TRY(pCtx, hipMemcpyAsync(&sum, pCtx->d_power, sizeof(double), hipMemcpyDeviceToHost, pCtx->stream));
+    HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+    *pdMeanPower = sum / (double)ullSamples;
     return 1;
 }
 

@@ -19,7 +19,7 @@ EXPORTS = [
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
     "if_fir_set_nco", "if_fir_get_nco", "if_fir_channelizer_process_device", "if_fir_host_alloc", "if_fir_host_free",
-    "if_fir_debug_fft_tables", "if_fir_debug_fft_schedule",
+    "if_fir_debug_fft_tables", "if_fir_debug_fft_schedule", "if_fir_power_device",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
 ]
@@ -107,6 +107,8 @@ def lib():
     L.if_fir_debug_fft_tables.restype = u32
     L.if_fir_debug_fft_schedule.argtypes = [u64, u32, ctypes.POINTER(ctypes.c_int64)]
     L.if_fir_debug_fft_schedule.restype = u8
+    L.if_fir_power_device.argtypes = [vp, vp, u64, ctypes.POINTER(ctypes.c_double)]
+    L.if_fir_power_device.restype = u8
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.if_fir_mc_owner.argtypes = [u32, u32]
     L.if_fir_mc_owner.restype = u32
@@ -216,6 +218,12 @@ class IfFir:
         f = ctypes.c_double(0.0)
         self._check(lib().if_fir_get_nco(self._ctx, ctypes.byref(f)))
         return float(f.value)
+
+    def power_device(self, dev_iq, samples):
+        """if_fir_power_device(): mean(|y|^2) of a device IQ buffer."""
+        p = ctypes.c_double(0.0)
+        self._check(lib().if_fir_power_device(self._ctx, ctypes.c_void_p(int(dev_iq)), int(samples), ctypes.byref(p)))
+        return float(p.value)
 
     def host_alloc(self, count, dtype=np.float32):
         """if_fir_host_alloc(): a page-locked numpy array of `count` elements (free it with host_free(array))."""

@@ -915,3 +915,28 @@ def test_multi_channel_front_int16_and_reset(fir, oracle, torch_cuda):
             assert l2 <= TOL and mx <= TOL, (c, l2, mx)
         with pytest.raises(fir.IfFirError):
             mc.set_input_format(7)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 100_001, 8_388_609])
+def test_in_band_power_measurement(fir, oracle, torch_cuda, n):
+    """if_fir_power_device (the measurement half of a level-control loop): mean |y|^2 of a device buffer,
+    accumulated in float64, against numpy's float64 mean; and on a filtered stream: the stop-band tone of the synthetic
+    input is gone, the in-band tone keeps its power."""
+    torch = torch_cuda
+    x = oracle.synth_iq(n, 91)
+    xd = torch.from_numpy(x).cuda()
+    with fir.IfFir(fir.bpf_design(255), 4, 0) as f:
+        got = f.power_device(xd.data_ptr(), n)
+        want = float(np.mean(np.sum(x.astype(np.float64).reshape(-1, 2) ** 2, axis=1)))
+        assert abs(got - want) <= 1e-12 * want, (got, want)
+        assert f.power_device(xd.data_ptr(), 0) == 0.0
+        with pytest.raises(fir.IfFirError):
+            f.power_device(xd.data_ptr() + 8, 1)          # misaligned
+        if n > 100_000:
+            y = torch.empty(2 * f.out_count(n), dtype=torch.float32, device="cuda")
+            m = f.process_device(xd.data_ptr(), y.data_ptr(), n)
+            f.synchronize()
+            p_out = f.power_device(y.data_ptr(), m)
+            # input: two tones of power 0.25 each + uniform noise (variance 2 * 0.25^2 / 12 * ... small); the 0.15-0.25
+            # band-pass keeps the 0.20 tone (gain 1) and a tenth of the noise
+            assert 0.25 < p_out < 0.26 and want > 0.5
