@@ -273,6 +273,10 @@ IF_FIR_API void if_fir_destroy(if_fir_ctx_t *pCtx)
     if (!pCtx)
         return;
     (void)hipSetDevice(pCtx->device);
+    // work queued on a caller's stream still reads the buffers freed below (hipFree waits for the device as well;
+    // this keeps the intent explicit and survives a caller that has already destroyed its stream)
+    if (pCtx->stream && pCtx->stream != pCtx->own_stream && hipStreamSynchronize(pCtx->stream) != hipSuccess)
+        (void)hipGetLastError();
     if (pCtx->own_stream)
     {
         (void)hipStreamSynchronize(pCtx->own_stream);
