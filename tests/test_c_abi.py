@@ -21,3 +21,28 @@ def test_c_host_program_on_the_c_abi(gpu_ok):
         run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
         assert run.returncode == 0, run.stdout + run.stderr
         assert "all checks passed" in run.stdout
+
+
+@pytest.mark.gpu
+def test_stream_filter_program(gpu_ok):
+    """qo-100-tools_amd/host/if_fir_pipe: stdin -> stdout stream filter (C, on the C ABI).  int16 samples in, NCO mix,
+    255 taps, decimate by 4, fed in calls of 4096 samples; the bytes coming out against the float64 oracle."""
+    import numpy as np
+    import __graft_entry__ as g
+    oracle = g.load_oracle()
+    fir = g.load_pkg().if_fir
+    exe = os.path.join(ROOT, "qo-100-tools_amd", "host", "if_fir_pipe")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "if_fir_pipe"])
+    n = 100_003
+    xi = np.clip(np.round(oracle.synth_iq(n, 7) * 14000.0), -32768, 32767).astype(np.int16)
+    run = subprocess.run([exe, "-t", "255", "-d", "4", "-b", "0.0:0.05", "-n", "0.2", "-i", "s16", "-c", "4096"],
+                         input=xi.tobytes(), capture_output=True, timeout=300)
+    assert run.returncode == 0, run.stderr.decode()
+    y = np.frombuffer(run.stdout, dtype=np.float32)
+    taps = fir.bpf_design(255, 0.0, 0.05)
+    ref = oracle.fir_nco_f64(taps, xi.astype(np.float32) * np.float32(2.0 ** -15), 4, oracle.nco_phase_word(0.2))
+    assert y.shape == ref.shape
+    l2, mx = oracle.err_metrics(y, ref)
+    assert l2 <= 1e-6 and mx <= 1e-6, (l2, mx)
+    assert b"100003 samples in, 25001 out" in run.stderr
