@@ -618,7 +618,7 @@ def test_uniform_filter_bank(fir, oracle, torch_cuda, t):
 def test_random_configurations_against_the_oracle(fir, oracle):
     """Sweep of random (taps, decimation, length, backend, piece cuts, input format, NCO) combinations: every result
     within SPEC tolerance of the float64 oracle, the bit-exact kernels equal to their order models."""
-    rng = np.random.default_rng(20261003)
+    rng = np.random.default_rng(int(os.environ.get("IF_FIR_TEST_SEED", "20261003")))   # other seeds: soak runs
     names = {fir.BACKEND_HIP_DIRECT: "direct", fir.BACKEND_HIP_TAPSPLIT: "tapsplit", fir.BACKEND_HIP_GENERIC: "generic",
              fir.BACKEND_HIP_FFT: "fft"}
     done = {k: 0 for k in names.values()}
