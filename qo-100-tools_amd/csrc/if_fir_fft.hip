@@ -243,15 +243,12 @@ __device__ __forceinline__ cf buf_load(srd_t rsrc, unsigned voff, unsigned soff)
     const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, IF_FIR_FFT_LOAD_AUX);
     return (cf){__uint_as_float(v[0]), __uint_as_float(v[1])};
 }
-// int16 IQ front-end: one dword = (I, Q) as two int16; value = int16 * 2^-15 (exact in float32)
-__device__ __forceinline__ cf buf_load_i16(srd_t rsrc, unsigned voff, unsigned soff)
-{
-    const int w = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, IF_FIR_FFT_LOAD_AUX);
-    return (cf){(float)(short)(w & 0xffff) * 0x1p-15f, (float)(w >> 16) * 0x1p-15f};
-}
+// int16 IQ front-end: one dword = (I, Q) as two int16; value = int16 * 2^-15
 __device__ __forceinline__ cf cvt_i16(unsigned w)
 {
-    return (cf){(float)(short)(w & 0xffffu) * 0x1p-15f, (float)((int)w >> 16) * 0x1p-15f};
+    // the 2^-15 of the sample format is folded into the H table (fft_build_tables, in_scale): a power of two commutes
+    // exactly with every float operation on the way, and the 64 multiplies per block are saved
+    return (cf){(float)(short)(w & 0xffffu), (float)((int)w >> 16)};
 }
 // Row `row` of a block (sample row*64 + lane) whose descriptor starts at the block's first sample.  float32 rows land
 // in r[row]; int16 rows stay RAW (one dword) in rw[row] and are converted when pass 1 consumes them — converting at
@@ -943,7 +940,7 @@ hipError_t launch_fft(const LaunchArgs &a)
 //   [32 KB, 64 KB)  hp [(i*16+k2)*64 + lane]   = FFT(taps)[(4*(lane/16)+i) + 16*(lane%16) + 256*k2] / 4096
 //   [64 KB, 66 KB)  tw2[k1*16 + n2]            = W256^(n2*k1)
 //   [66 KB, 82 KB)  twd, twe: twiddles of the decimate-by-4 1024-point inverse
-void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta,
+void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale,
                       float *tables /* FFT_TABLE_FLOATS floats */)
 {
     const double PI2 = 6.283185307179586476925286766559;
@@ -1013,8 +1010,8 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                     re += hr * ct[e] - hi * st[e];
                     im += hr * st[e] + hi * ct[e];
                 }
-                hd[2 * ((i * 16 + k2) * 64 + lane) + 0] = re / 4096.0;
-                hd[2 * ((i * 16 + k2) * 64 + lane) + 1] = im / 4096.0;
+                hd[2 * ((i * 16 + k2) * 64 + lane) + 0] = re / 4096.0 * in_scale; // in_scale: 2^-15 for raw int16 samples
+                hd[2 * ((i * 16 + k2) * 64 + lane) + 1] = im / 4096.0 * in_scale;
             }
     if (D != 4)
     {

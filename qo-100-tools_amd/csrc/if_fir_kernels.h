@@ -83,7 +83,7 @@ struct FftSchedule
 };
 void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s); // host-only: run-queue layout of a launch
 hipError_t launch_fft(const LaunchArgs &a);
-void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, float *tables);
+void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale, float *tables);
 
 hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, int in_i16,
                           hipStream_t stream);

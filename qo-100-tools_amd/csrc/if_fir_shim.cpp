@@ -124,8 +124,9 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
         return 0;
     }
     // NCO row phasors: per kept output for the decimate-by-4 kernel, per full-rate output for all others
+    // int16 input: the kernel leaves the samples unscaled and the table carries the format's 2^-15
     if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (ctx->D == 4 ? 4u : 1u),
-                             tab);
+                             ctx->in_i16 ? 0x1p-15 : 1.0, tab);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
@@ -676,7 +677,7 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps
     if (!pfTaps || !pfOut || ulOutFloats < (uint32_t)if_fir::FFT_TABLE_FLOATS ||
         !if_fir::fft_supported((int)ulTaps, (int)ulDecimation))
         return 0;
-    if_fir::fft_build_tables(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, (int)ulDecimation, ulNcoDelta, pfOut);
+    if_fir::fft_build_tables(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, (int)ulDecimation, ulNcoDelta, 1.0, pfOut);
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
 }
 
@@ -980,6 +981,13 @@ IF_FIR_API uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat
     }
     const int old = pCtx->in_i16;
     pCtx->in_i16 = (ulFormat == IF_FIR_INPUT_I16);
+    if (old != pCtx->in_i16 && pCtx->d_fft_tables) // the H table carries the sample format's scale: rebuilt on demand
+    {
+        HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+        HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+        (void)hipFree(pCtx->d_fft_tables);
+        pCtx->d_fft_tables = nullptr;
+    }
     const uint32_t b = resolve_backend(pCtx, pCtx->backend_req);
     if (!backend_ok(pCtx, b))
     {
