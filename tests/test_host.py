@@ -209,3 +209,32 @@ def test_overlap_save_run_queue_schedule_tiles_the_blocks(fir):
             assert nxt == nblocks, (nblocks, wgs, s)
             for q in (s["tickets"], s["tickets"] + 1, s["tickets"] + 5000):
                 assert run_range(q, s, nblocks)[0] >= nblocks
+
+
+def test_bench_line_contract_on_the_committed_run():
+    """The bench.py JSON line of the last profiled run (profiles/*_bench.json, produced on the GPU box) carries every
+    field the driver's contract names, with the right types, and its numbers are mutually consistent."""
+    import glob
+    import json
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+    assert paths, "no committed bench line under profiles/"
+    line = [ln for ln in open(paths[-1]).read().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), (key, type(d[key]))
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["dtype"] == "f32" and d["unit"] == "MSamples/s" and "255-tap" in d["metric"]
+    assert "workload" in d["config"] and "2^28" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1.0
+    assert r["traffic"] is None or 0.9 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.3 * r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    # value = samples of all ranks / wall time per step
+    n = d["config"]["samples_per_channel"] * d["config"].get("channels", d["n_gpus"])
+    assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    assert d["parity"]["whole_output"]["ok"] is True
