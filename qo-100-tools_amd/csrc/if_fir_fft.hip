@@ -875,8 +875,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 }
 
 // D = 1 and D = 4 have their own kernels; any other decimation runs the full-rate kernel with a selecting store.
-// Taps: the first T-1 outputs of a 4096-point block are discarded, in whole 64-sample rows (4, 16, 32 or 48 of the 64):
-// up to 257 taps cost 6 % of the block, 1025 taps 25 %, 2049 taps half, 3073 taps three quarters.
+// Taps: the first T-1 outputs of a 4096-point block are discarded, in whole 64-sample rows (4, 8, 16, 32 or 48 of the
+// 64): up to 257 taps cost 6 % of the block, 513 taps 12.5 %, 1025 taps 25 %, 2049 taps half, 3073 taps three quarters.
 bool fft_supported(int T, int D)
 {
     return D >= 1 && D <= 64 && T >= 1 && T <= 3073;
@@ -884,7 +884,7 @@ bool fft_supported(int T, int D)
 
 int fft_overlap_rows(int T)
 {
-    return (T - 1 <= 256) ? 4 : (T - 1 <= 1024) ? 16 : (T - 1 <= 2048) ? 32 : 48;
+    return (T - 1 <= 256) ? 4 : (T - 1 <= 512) ? 8 : (T - 1 <= 1024) ? 16 : (T - 1 <= 2048) ? 32 : 48;
 }
 
 template <int ROWS>
@@ -929,6 +929,7 @@ hipError_t launch_fft(const LaunchArgs &a)
     switch (fft_overlap_rows(a.T))
     {
     case 4: return launch_fft_rows<4>(a);
+    case 8: return launch_fft_rows<8>(a);
     case 16: return launch_fft_rows<16>(a);
     case 32: return launch_fft_rows<32>(a);
     default: return launch_fft_rows<48>(a);

@@ -220,7 +220,7 @@ def test_caller_stream(fir, oracle, torch_cuda):
         assert np.array_equal(out.cpu().numpy(), oracle.fir_f32fma(taps, x, 1, **SEG))
 
 
-@pytest.mark.parametrize("t", [1023, 255, 127, 1025, 257, 31, 1])
+@pytest.mark.parametrize("t", [1023, 255, 127, 1025, 257, 31, 1, 259, 513, 515])
 def test_fft_backend_vs_oracle(fir, oracle, t):
     """Overlap-save FFT-FIR: no bit-exact model, SPEC §3 tolerance against the float64 oracle; compared
     with the direct/generic form on the same input."""
@@ -303,7 +303,7 @@ def test_fft_backend_rejects_unsupported(fir):
             f.set_backend(fir.BACKEND_HIP_FFT)        # more than 3073 taps: less than a quarter of a block would be new
 
 
-@pytest.mark.parametrize("t", [255, 127, 1023, 257])
+@pytest.mark.parametrize("t", [255, 127, 1023, 257, 259, 513])
 def test_fft_backend_decimate4_vs_oracle(fir, oracle, t):
     """Overlap-save with the decimation folded into the frequency domain (1024-point inverse): SPEC tolerance against
     the float64 oracle, one-shot and in ragged pieces (odd piece lengths exercise every decimation phase n0)."""
@@ -568,7 +568,7 @@ def test_nco_golden_int16_complex_taps_and_refusals(fir, oracle):
             f.set_backend(fir.BACKEND_HIP_DIRECT)  # and the other way round
 
 
-@pytest.mark.parametrize("t", [255, 1023, 63])
+@pytest.mark.parametrize("t", [255, 1023, 63, 511])
 def test_uniform_filter_bank(fir, oracle, torch_cuda, t):
     """if_fir_channelizer_process_device = the channels' NCO + prototype + decimate-by-4 results from one
     pass over the input.  Every channel against the float64 oracle (NCO phase word slot * 2^28), in ragged pieces (odd
