@@ -138,6 +138,54 @@ static float time_ms(F launch, int reps)
     return ms / reps;
 }
 
+// 16 independent v_pk_add_f32 x 4 per iteration (the butterfly instruction of the FFT kernel)
+__global__ void k_pkadd(f2 *out, float h0)
+{
+    f2 a[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) a[i] = (f2){threadIdx.x * 1e-9f + i, 1.f};
+    f2 x = {threadIdx.x * 1e-3f + h0, 0.5f};
+    for (int it = 0; it < ITERS; it++)
+    {
+#pragma unroll
+        for (int rep = 0; rep < 4; rep++)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+    }
+    f2 s = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// 32 v_permlane32_swap + 32 v_permlane16_swap per iteration on 16 independent register pairs (exchange 1 of the FFT)
+__global__ void k_permlane(f2 *out, float h0)
+{
+    unsigned a[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        a[i] = threadIdx.x * 3 + i;
+        b[i] = threadIdx.x * 5 + i + (unsigned)h0;
+    }
+    for (int it = 0; it < ITERS; it++)
+    {
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+            {
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(b[i]));
+                asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(b[i]));
+            }
+    }
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += a[i] ^ b[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (f2){(float)s, 0.f};
+}
+
 int main()
 {
     hipDeviceProp_t p;
@@ -153,7 +201,7 @@ int main()
         const int block = 256; // 4 waves -> one per SIMD; blocks/CU = wps
         const int grid = cus * wps;
         const double instr = (double)ITERS * 64; // per wave
-        struct { const char *name; double flop_per_instr_lane; int which; } ks[] = {{"fma", 2, 0}, {"pkfma_v", 4, 1}, {"pkfma_s", 4, 2}, {"mix", 4, 3}};
+        struct { const char *name; double flop_per_instr_lane; int which; } ks[] = {{"fma", 2, 0}, {"pkfma_v", 4, 1}, {"pkfma_s", 4, 2}, {"mix", 4, 3}, {"pkadd", 2, 4}, {"permlane", 0, 5}};
         for (auto &k : ks)
         {
             float ms = time_ms([&]() {
@@ -161,6 +209,8 @@ int main()
                 if (k.which == 1) hipLaunchKernelGGL(k_pkfma_v, dim3(grid), dim3(block), 0, 0, out, 0.999f);
                 if (k.which == 2) hipLaunchKernelGGL(k_pkfma_s, dim3(grid), dim3(block), 0, 0, out, h);
                 if (k.which == 3) hipLaunchKernelGGL(k_mix, dim3(grid), dim3(block), 17 * 256 * 16, 0, out, h);
+                if (k.which == 4) hipLaunchKernelGGL(k_pkadd, dim3(grid), dim3(block), 0, 0, out, 0.999f);
+                if (k.which == 5) hipLaunchKernelGGL(k_permlane, dim3(grid), dim3(block), 0, 0, out, 0.999f);
             }, 5);
             const double waves = (double)grid * block / 64;
             const double flops = waves * instr * 64 * k.flop_per_instr_lane;
