@@ -134,11 +134,118 @@ def cpu_baseline(taps_arr, decim, budget_s=10.0):
                       (taps_arr.size, decim, reps, "-march=native" if handle is not None else "x86-64-v3")}
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch_argv(gpus, argv, port):
+    """argv of the child that runs this script as `gpus` ranks (one per GPU) under torch.distributed.run."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv):
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (never exec: under
+    rocprofv3 the preloaded library has already initialised the GPU in this process), relay rank 0's JSON line and
+    return the child's exit code.  Nothing in this process has touched the GPU at this point."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = self_launch_argv(gpus, argv, free_port())
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    out = proc.communicate()[0].decode(errors="replace")
+    lines = []
+    for ln in out.splitlines():
+        try:
+            if "metric" in json.loads(ln):
+                lines.append(ln)
+        except ValueError:
+            sys.stderr.write(ln + "\n")       # launcher chatter is not part of the one-line contract
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return proc.returncode if proc.returncode else (0 if lines else 1)
+
+
+def dry_run(args, rank, world, json_fd):
+    """--dry-run: the launch / barrier / MAX-over-ranks / one-JSON-line plumbing on the CPU (gloo), with a timing stub
+    in place of the filter (no GPU, no oracle, no filtering: the line says so and carries no roofline)."""
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    taps_n, decim, log2n, desc = WORKLOADS[args.workload]
+    n = 1 << 12
+    total_channels = args.channels if args.channels else world
+    if total_channels < world:
+        raise SystemExit("--channels must be at least the number of GPUs")
+    owned = [c for c in range(total_channels) if c % world == rank]
+
+    def step_stub():
+        for _ in owned:
+            time.sleep(1e-4)
+
+    for _ in range(args.warmup):
+        step_stub()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_stub()
+    if use_dist:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t[0])
+    if rank == 0:
+        line = {"metric": "complex-IQ MSamples/s through %d-tap FIR" % taps_n,
+                "value": round(total_channels * n / (wall / args.steps) / 1e6, 3), "unit": "MSamples/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "strong" if args.channels else "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "none", "dry_run": True,
+                "config": {"workload": "DRY RUN of the launch path: a sleep stands for the filter (%s)" % desc,
+                           "name": args.workload, "channels": total_channels, "channels_on_rank0": len(owned),
+                           "parallelism": "channel c on rank c mod %d, no data-path collective" % world}}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def time_config(fir, name, backend, x, dev, stream, steps, warmup, names):
+    """One more BASELINE config timed on the resident synthetic stream (extra.configs; never part of `value`)."""
+    taps_n, decim, log2n, desc = WORKLOADS[name]
+    n = 1 << log2n
+    taps = fir.bpf_design(taps_n)
+    with fir.IfFir(taps, decim, 0, device=dev.index, backend=backend) as fc:
+        fc.set_stream(stream.cuda_stream)
+        y = torch.empty(2 * fc.out_count(n), dtype=torch.float32, device=dev)
+        for _ in range(warmup):
+            fc.process_device(x.data_ptr(), y.data_ptr(), n)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            fc.process_device(x.data_ptr(), y.data_ptr(), n)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        nonzero = bool((y[:1 << 16] != 0).any().item())
+        b = names[fc.get_backend()]
+    del y
+    gbs = algorithmic_bytes_per_sample(decim) * n / (ms * 1e-3) / 1e9
+    return {"backend": b, "kernel_ms": round(ms, 4), "steps": steps, "msamples_per_s": round(n / ms / 1e3, 1),
+            "hbm_gbs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "valu_tflops_direct_form_equivalent": round(algorithmic_flops_per_sample(taps_n, decim) * n / (ms * 1e-3) / 1e12, 2),
+            "output_nonzero": nonzero}
+
+
 def main():
     # Everything except the final JSON line goes to stderr: RCCL prints a version banner on stdout at communicator
     # creation, which would break the one-line contract.
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -156,16 +263,24 @@ def main():
                     help="fixed TOTAL number of channels, channel c on rank c mod N, each rank filters its channels back "
                          "to back (BASELINE configs[3]: 8 channels on 8/4/2/1 GPUs; strong scaling).  Default: one "
                          "channel per GPU (weak scaling)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the launch path on the CPU (gloo, a sleep instead of the filter); no GPU needed")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the other single-GPU BASELINE configs timed after the headline (extra.configs)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become the launcher (child process; nothing here has touched the GPU yet)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world, json_fd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libif_fir has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -383,12 +498,17 @@ def main():
         flops_per_launch = algorithmic_flops_per_sample(taps_n, decim) * n * len(owned)
         achieved_gbs = bytes_per_launch / (dev_ms_max * 1e-3) / 1e9
         achieved_tf = flops_per_launch / (dev_ms_max * 1e-3) / 1e12
-        traffic = None
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 key = args.workload + (":fir_fft" if f.get_backend() == fir.BACKEND_HIP_FFT else ":fir_direct")
-                traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath)).get(key, {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_src = ("NOT measured in this run: TCC counters of kernel %s from the committed rocprofv3 "
+                                   "passes profiles/%s_* (another box), file profiles/traffic.json"
+                                   % (rec.get("kernel"), rec.get("round")))
             except Exception:
                 traffic = None
         # parity spot check (oracle as checker only): first 4096 outputs of this rank's last step vs the order model.
@@ -430,6 +550,7 @@ def main():
                        "device": f.device_info()},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel_ms": round(dev_ms_max, 4),
                          "kernel_ms_median": round(float(np.median(per_step)), 4),
                          "kernel_ms_min": round(float(np.min(per_step)), 4),
@@ -464,6 +585,20 @@ def main():
                 del dst
             except Exception as e:   # noqa: BLE001 - context only, never fatal
                 extra["hbm_copy_on_this_box"] = {"error": repr(e)}
+        if world == 1 and not args.no_extra_configs and args.workload == "fir255_dec4_2p28" and not args.channels:
+            # the other single-GPU BASELINE configs on the same resident stream: AUTO and the comparison form
+            # (direct form where the unrolled kernels exist, else the tap-split kernel of the north_star's wording)
+            cfgs = {}
+            try:
+                torch.cuda.empty_cache()
+                for cname, forms in (("fir127_2p26", (("auto", fir.BACKEND_AUTO, 20, 5), ("direct", fir.BACKEND_HIP_DIRECT, 20, 5))),
+                                     ("fir1023_2p28", (("auto", fir.BACKEND_AUTO, 20, 5), ("tapsplit", fir.BACKEND_HIP_TAPSPLIT, 2, 1)))):
+                    cfgs[cname] = {"workload": WORKLOADS[cname][3]}
+                    for label, b, st, wu in forms:
+                        cfgs[cname][label] = time_config(fir, cname, b, x, dev, stream, st, wu, names)
+            except Exception as e:   # noqa: BLE001 - context only, never fatal
+                cfgs["error"] = repr(e)
+            extra["configs"] = cfgs
         if extra:
             line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:

@@ -428,6 +428,13 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     };
     int64_t blk, blk_end;
     run_range((int64_t)blockIdx.x * FFT_WAVES + wid, blk, blk_end);
+    // diag 32 (development, results stay correct): static wave-interleaved blocks, no queue: block = it * waves + wave
+    const bool static_map = (diag & 32) != 0;
+    if (static_map)
+    {
+        blk = (int64_t)blockIdx.x * FFT_WAVES + wid;
+        blk_end = blk + 1;
+    }
     cf r[64];
     unsigned rw[64]; // raw int16 pairs of the block being loaded (I16 input only)
     bool loaded = false; // the rows of `blk` are already in flight (issued by the previous iteration's epilogue)
@@ -519,7 +526,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         exchange2(r, xb, lane);
         FFT_STAMP(4);
         int64_t blk_next = blk + 1;
-        if (blk_next >= blk_end)
+        if (static_map)
+        {
+            blk_next = blk + waves_total;
+            blk_end = blk_next + 1;
+        }
+        else if (blk_next >= blk_end)
         {
             run_range((int64_t)waves_total + (int64_t)queue_ticket(queue, ticket_base, lane), blk_next, blk_end);
         }
@@ -869,8 +881,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
                        DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a), DECN ? 0u - a.nco_word : nco_delta(a),
                        a.chan ? *a.chan : ChanArgs{}, base, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M);
     const hipError_t le = hipGetLastError();
-    if (le != hipSuccess && a.queue_valid)
-        *a.queue_valid = false; // nothing ran: the counter did not advance
+    if ((le != hipSuccess || (a.diag & 32)) && a.queue_valid)
+        *a.queue_valid = false; // nothing ran (or the static diagnostic mapping): the counter did not advance as planned
     return le;
 }
 

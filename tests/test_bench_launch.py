@@ -1,0 +1,51 @@
+"""CPU tests of bench.py's launch path: `python3 bench.py --gpus N` must work as the driver runs it (no launcher around
+it): the parent spawns the ranks as a child process and relays rank 0's single JSON line.  --dry-run replaces the
+filter by a sleep (gloo, no GPU, no oracle), so only the plumbing is exercised here."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run_bench(*argv, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK")):
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    p = subprocess.run([sys.executable, BENCH] + list(argv), capture_output=True, text=True, env=env, timeout=300)
+    return p
+
+
+def test_self_launch_argv_is_the_drivers_command():
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = bench.self_launch_argv(4, ["--gpus", "4", "--steps", "7"], 29777)
+    assert argv[0] == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and argv[argv.index("--nproc-per-node") + 1] == "4"
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29777"
+    assert argv[-5:] == [BENCH, "--gpus", "4", "--steps", "7"]
+
+
+def test_gpus2_without_a_launcher_prints_exactly_one_json_line():
+    p = run_bench("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["dry_run"] is True
+    assert line["scaling"] == "weak" and line["config"]["channels"] == 2 and line["value"] > 0
+
+
+def test_channels_form_is_strong_scaling():
+    p = run_bench("--gpus", "2", "--channels", "8", "--dry-run", "--steps", "2", "--warmup", "0")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["config"]["channels"] == 8 and line["config"]["channels_on_rank0"] == 4
+
+
+def test_single_gpu_dry_run_and_failing_child_exit_code():
+    p = run_bench("--dry-run", "--steps", "2", "--warmup", "0")
+    assert p.returncode == 0 and json.loads(p.stdout.strip())["n_gpus"] == 1
+    # a child that fails (fewer channels than GPUs) must surface as a non-zero exit code and no JSON line
+    p = run_bench("--gpus", "2", "--channels", "1", "--dry-run")
+    assert p.returncode != 0 and not p.stdout.strip()

@@ -5,8 +5,8 @@ cp qo-100-tools_amd/libif_fir.so /tmp/libif_fir_orig.so
 for lib in qo-100-tools_amd/libif_fir_ab_*.so; do
   cp "$lib" qo-100-tools_amd/libif_fir.so
   echo "== $lib"
-  for w in "$@"; do python tools/sweep.py $w 100 2>/dev/null | grep variant; done
+  for w in "$@"; do python tools/sweep.py $w ${VARIANTS:-100} 2>/dev/null | grep variant; done
 done
 cp /tmp/libif_fir_orig.so qo-100-tools_amd/libif_fir.so
 echo "== baseline"
-for w in "$@"; do python tools/sweep.py $w 100 2>/dev/null | grep variant; done
+for w in "$@"; do python tools/sweep.py $w ${VARIANTS:-100} 2>/dev/null | grep variant; done
