@@ -148,7 +148,8 @@ uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulW
  * number of floats written, 0 if the (taps, decimation) pair is not served by that kernel.  Used by the CPU tests. */
 uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
                                  uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats);
-/* host-only diagnostic: run-queue layout of an overlap-save launch (pllOut[6] = RA, nA, RB, nB, tickets, workgroups) */
+/* host-only diagnostic: block-queue layout of an overlap-save launch: pllOut[6] = blocks per group, groups, static groups
+ * per workgroup, 0, upper bound of the global ticket counter, workgroups */
 uint8_t if_fir_debug_fft_schedule(uint64_t ullBlocks, uint32_t ulWorkgroups, int64_t *pllOut);
 /* "gfx950", CU count, etc.: writes a short description of the context's device */
 uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOutBytes);

@@ -161,7 +161,9 @@ constexpr int FFT_WAVES = 8;
 constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_TWD = 65536 + 2048, LDS_TWE = LDS_TWD + 8192,
               LDS_NCO = LDS_TWE + 8192, LDS_XB = LDS_NCO + 512;
 static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
-constexpr int FFT_LDS_BYTES = LDS_XB + FFT_WAVES * XBUF;
+constexpr int LDS_Q = LDS_XB + FFT_WAVES * XBUF; // workgroup block queue: slot counter (16 B) + ring of group entries
+constexpr int Q_RING = 16;
+constexpr int FFT_LDS_BYTES = LDS_Q + 16 + Q_RING * 8;
 
 __device__ __forceinline__ void exchange1_fwd(cf (&r)[64])
 {
@@ -269,17 +271,51 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
     __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, IF_FIR_FFT_STORE_AUX);
 }
 
-// next run of this wave: one returning atomic add by lane 0, waited for on the spot.  It is taken at the last block of
-// a run, before that block's pass 3 issues the next rows, so hipcc's vmcnt(0) behind it drains nothing but the atomic.
-// (An earlier version issued the atomic a run ahead through inline asm and waited later: the compiler cannot know
-// that the destination VGPR is still in flight and may spill or copy it before the value lands -- it did, once a
-// change made the kernel spill: every wave then stopped after its first run.  Do not bring that back.)
-__device__ __forceinline__ unsigned queue_ticket(unsigned int *queue, unsigned base, int lane)
+// ---- block queue (two levels) -----------------------------------------------------------------------------------
+// Blocks are handed out in GROUPS of 8 consecutive blocks, one group at a time per workgroup, groups in global order:
+// at any moment the chip works on one compact window of the stream (DRAM pages and the overlap rows of neighbouring
+// blocks are shared by waves that run at the same time), and no wave holds work another one could do.
+//   * level 1, LDS: a wave takes the next SLOT of its workgroup (ds_add_rtn): slot s = block s % 8 of local group s / 8;
+//   * level 2, global: the wave that takes slot 0 of local group g fetches the global group of local group g + 2 with
+//     one returning atomic (waited for on the spot: it sits where nothing else of this wave is in flight) and
+//     publishes it in an LDS ring; local groups 0 and 1 are static (workgroup b: global groups b and wgs + b).
+// One global atomic per 8 blocks (a single address takes ~88 atomics/us; 70 k blocks in 0.5 ms would be 140/us), two
+// groups of slack before anybody needs its result.  A ring entry is {local group, global group} in one 8-byte LDS word.
+__host__ __device__ __forceinline__ constexpr int64_t fft_static_group(int local_group, int64_t wg, int64_t wgs)
 {
-    unsigned t = 0;
+    return local_group == 0 ? wg : wgs + wg;
+}
+__device__ __forceinline__ int64_t queue_take(char *smem, unsigned int *gqueue, int lane)
+{
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(smem + LDS_Q);
+    unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16);
+    unsigned s = 0;
     if (lane == 0)
-        t = atomicAdd(queue, 1u) - base; // the counter runs on from launch to launch (no memset): base = tickets so far
-    return __builtin_amdgcn_readfirstlane(t);
+        s = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    s = __builtin_amdgcn_readfirstlane(s);
+    const unsigned g = s >> 3, j = s & 7u;
+    if (j == 0)
+    {
+        unsigned t = 0;
+        if (lane == 0)
+            t = atomicAdd(gqueue, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const unsigned long long e = ((unsigned long long)(2u * gridDim.x + t) << 32) | (unsigned long long)(g + 2u);
+        if (lane == 0)
+            __hip_atomic_store(&ring[(g + 2u) & (Q_RING - 1)], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // the entry of group g was published by the taker of slot 0 of group g - 2 (or at kernel start): it is almost
+    // always there already; its writer waits for nothing but its own global atomic, so this loop ends
+    unsigned long long e;
+    for (;;)
+    {
+        e = __hip_atomic_load(&ring[g & (Q_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((unsigned)e == g)
+            break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const unsigned gg = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
+    return (int64_t)gg * 8 + j;
 }
 
 // decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
@@ -331,10 +367,9 @@ template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN, bool DECN>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
-                                                        int32_t waves_total, int32_t RA, int32_t nA, int32_t RB, int32_t nB,
                                                         unsigned int *queue, unsigned long long *dbg, int32_t diag,
                                                         uint32_t nco_phi0, uint32_t nco_delta, ChanArgs chan,
-                                                        uint32_t ticket_base, void *__restrict__ hist_out,
+                                                        uint32_t qsel, void *__restrict__ hist_out,
                                                         int32_t decn, int32_t decn_n0, int64_t decn_m)
 {
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
@@ -355,8 +390,24 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         f4v_t *dst = reinterpret_cast<f4v_t *>(smem);
         for (int i = threadIdx.x; i < LDS_XB / 16; i += 512)
             dst[i] = src[i];
+        // block queue: slot counter 0; local groups 0 and 1 are static, the rest of the ring is empty
+        if (threadIdx.x < Q_RING)
+        {
+            unsigned long long e = ~0ull;
+            if (threadIdx.x < 2)
+                e = ((unsigned long long)fft_static_group(threadIdx.x, blockIdx.x, gridDim.x) << 32) | threadIdx.x;
+            reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16)[threadIdx.x] = e;
+        }
+        if (threadIdx.x == 0)
+        {
+            *reinterpret_cast<unsigned int *>(smem + LDS_Q) = 0u;
+            // the other global counter is the next launch's: zero it here (this launch never touches it)
+            if (blockIdx.x == 0)
+                queue[qsel ^ 1u] = 0u;
+        }
     }
     __syncthreads();
+    unsigned int *gqueue = queue + qsel;
     // streaming state: the history of the NEXT call = the last T-1 samples of (history || input), written to the other
     // ping-pong buffer by one wave (everything it reads is read-only in this launch); spares a launch per call
     if (hist_out && blockIdx.x == 0 && wid == 0)
@@ -403,37 +454,24 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #else
 #define FFT_STAMP(slot) (void)0
 #endif
-    // Work distribution: wave w starts with ticket w; further tickets come from one atomic counter, one per RUN of
-    // blocks (queue_ticket() at the last block of a run).  (One ticket per BLOCK saturates the counter: a single address takes
-    // ~88 atomics/us, 70k blocks would cost 0.8 ms by themselves.)
-    // guided schedule: tickets [0, nA) are runs of RA blocks, the next nB tickets runs of RB blocks, the rest single
-    // blocks, so that the tail of the launch is handed out in small pieces and all waves finish together
-    auto run_range = [&](int64_t q, int64_t &b0, int64_t &b1) {
-        if (q < nA)
-        {
-            b0 = q * RA;
-            b1 = b0 + RA;
-        }
-        else if (q < (int64_t)nA + nB)
-        {
-            b0 = (int64_t)nA * RA + (q - nA) * RB;
-            b1 = b0 + RB;
-        }
-        else
-        {
-            b0 = (int64_t)nA * RA + (int64_t)nB * RB + (q - nA - nB);
-            b1 = b0 + 1;
-        }
-        b1 = b1 < nblocks ? b1 : nblocks;
-    };
-    int64_t blk, blk_end;
-    run_range((int64_t)blockIdx.x * FFT_WAVES + wid, blk, blk_end);
+    // whole-launch stamps per wave (only with a debug buffer: if_fir_debug_stamps): realtime (100 MHz) and shader clock
+    unsigned long long st_r0 = 0, st_c0 = 0;
+    if (dbg)
+    {
+        st_r0 = __builtin_amdgcn_s_memrealtime();
+        st_c0 = __builtin_amdgcn_s_memtime();
+    }
+    // Work distribution: see queue_take()
+    const int32_t waves_total = (int32_t)gridDim.x * FFT_WAVES;
+    int64_t blk = (diag & 32) ? 0 : queue_take(smem, gqueue, lane);
     // diag 32 (development, results stay correct): static wave-interleaved blocks, no queue: block = it * waves + wave
     const bool static_map = (diag & 32) != 0;
+    // diag 64 (with 32): only waves 0-3 of each workgroup work = one wave per SIMD (occupancy experiment)
+    const int act_waves = (diag & 64) ? FFT_WAVES / 2 : FFT_WAVES;
+    const int64_t static_stride = (int64_t)(waves_total / FFT_WAVES) * act_waves;
     if (static_map)
     {
-        blk = (int64_t)blockIdx.x * FFT_WAVES + wid;
-        blk_end = blk + 1;
+        blk = (wid < act_waves) ? (int64_t)blockIdx.x * act_waves + wid : nblocks;
     }
     cf r[64];
     unsigned rw[64]; // raw int16 pairs of the block being loaded (I16 input only)
@@ -528,12 +566,13 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         int64_t blk_next = blk + 1;
         if (static_map)
         {
-            blk_next = blk + waves_total;
-            blk_end = blk_next + 1;
+            blk_next = blk + static_stride;
         }
-        else if (blk_next >= blk_end)
+        else
         {
-            run_range((int64_t)waves_total + (int64_t)queue_ticket(queue, ticket_base, lane), blk_next, blk_end);
+            // taken here: the block's own rows have all landed and the next block's are not issued yet, so the wait
+            // behind the (rare) global atomic inside drains nothing
+            blk_next = queue_take(smem, gqueue, lane);
         }
         const int64_t s0n = blk_next * L - OVL + n0;
         // (filter bank on int16 input: the raw next block would need 64 more registers next to the 64 held across the
@@ -793,33 +832,33 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         loaded = next_fast;
         blk = blk_next;
     }
+#ifndef IF_FIR_FFT_STAMPS
+    if (dbg && lane == 0)
+    {
+        unsigned long long *d = dbg + 4 * ((size_t)blockIdx.x * FFT_WAVES + wid);
+        d[0] = st_r0;
+        d[1] = __builtin_amdgcn_s_memrealtime();
+        d[2] = st_c0;
+        d[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
-// Guided schedule of the run queue (see the kernel): ticket q < nA is a run of RA blocks, the next nB tickets are runs
-// of RB blocks, the rest single blocks: ~80 % of the blocks in long runs (the counter stays far from its ~88 tickets/us
-// limit), small pieces at the end keep the tail short.  `tickets` is also the exact number of counter increments of a
-// launch (every wave that runs takes one ticket per run, the last one beyond the end), which is what lets launches
-// share a running counter.
+// Host view of the block queue (see queue_take): groups of FFT_WAVES blocks in global order; workgroup b starts with
+// global groups b and wgs + b (static), every further group of a workgroup is global group 2 * wgs + ticket.  Tickets
+// keep being drawn past the end (a wave learns that it is done by receiving a block >= nblocks), at most one per group
+// slot 0 taken, so a launch draws fewer than groups + 2 * wgs of them; the counter is re-zeroed by the launch before.
 void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s)
 {
-    const int64_t waves_max = wgs_max * FFT_WAVES;
-    int64_t RA = nblocks / (waves_max * 4);
-    RA = RA < 1 ? 1 : (RA > 8 ? 8 : RA);
-    const int64_t RB = RA >= 4 ? 2 : 1;
-    int64_t nA = (nblocks * 8 / 10) / RA;
-    if (nA < waves_max && nA * RA < nblocks)
-        nA = (nblocks / RA < waves_max) ? nblocks / RA : waves_max; // every wave starts with a full run when possible
-    int64_t nB = RB > 1 ? (nblocks * 15 / 100) / RB : 0;
-    if (nA * RA + nB * RB > nblocks)
-        nB = (nblocks - nA * RA) / RB;
-    s.RA = RA;
-    s.nA = nA;
-    s.RB = RB;
-    s.nB = nB;
-    s.tickets = nA + nB + (nblocks - nA * RA - nB * RB);
-    s.wgs = wgs_max;
-    if (s.wgs * FFT_WAVES > s.tickets)
-        s.wgs = (s.tickets + FFT_WAVES - 1) / FFT_WAVES;
+    const int64_t groups = (nblocks + FFT_WAVES - 1) / FFT_WAVES;
+    s.RA = FFT_WAVES; // blocks per group
+    s.nA = groups;
+    s.RB = 2;         // static groups per workgroup
+    s.nB = 0;
+    s.wgs = groups < wgs_max ? groups : wgs_max;
+    if (s.wgs < 1)
+        s.wgs = 1;
+    s.tickets = groups + 2 * s.wgs; // upper bound of the counter at the end of the launch
 }
 
 template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN = false, bool DECN = false>
@@ -828,21 +867,12 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
     constexpr int LOUT = DEC4 ? L / 4 : L;
-    static bool attr_done[16] = {false};
-    static int cus[16] = {0};
-    const int dev = a.device & 15;
-    if (!attr_done[dev])
+    static DeviceSetup setup;
+    int ncus = 0;
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FFT_LDS_BYTES);
+        const hipError_t e = device_setup(setup, a.device, reinterpret_cast<const void *>(kern), FFT_LDS_BYTES, &ncus);
         if (e != hipSuccess)
             return e;
-        hipDeviceProp_t prop;
-        e = hipGetDeviceProperties(&prop, a.device);
-        if (e != hipSuccess)
-            return e;
-        cus[dev] = prop.multiProcessorCount;
-        attr_done[dev] = true;
     }
     // DECN: the kernel runs at full rate over the N inputs (blocks, run queue, history as for D = 1) and keeps every
     // D-th output, the first one at full-rate index n0
@@ -851,38 +881,36 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
     if (nblocks <= 0)
         return hipSuccess;
-    const int64_t wgs_max = (a.grid_limit > 0 && a.grid_limit < cus[dev]) ? a.grid_limit : cus[dev];
+    const int64_t wgs_max = (a.grid_limit > 0 && a.grid_limit < ncus) ? a.grid_limit : ncus;
     FftSchedule sch;
     fft_schedule(nblocks, wgs_max, sch);
-    const int64_t RA = sch.RA, nA = sch.nA, RB = sch.RB, nB = sch.nB, tickets = sch.tickets, wgs = sch.wgs;
-    // the ticket counter is not re-zeroed: every launch consumes exactly `tickets` increments (each wave that runs
-    // takes one ticket per run, the last one beyond the end), so the next launch starts from a known base
-    uint32_t base = 0;
+    const int64_t wgs = sch.wgs;
+    // two global counters used alternately: a launch draws from one and zeroes the other for the launch behind it
+    // (same stream, so it has finished before that one starts); after anybody else touched the words, start over
+    uint32_t qsel = 0;
     if (a.queue_base && a.queue_valid && *a.queue_valid)
-        base = *a.queue_base;
+        qsel = *a.queue_base & 1u;
     else
     {
-        base = a.queue_seed; // 0 in production; the tests start near 2^32 to cross the wrap of the 32-bit counter
-        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.queue, (int)base, 4, a.stream);
+        hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);
         if (e != hipSuccess)
             return e;
     }
     if (a.queue_base && a.queue_valid)
     {
-        *a.queue_base = base + (uint32_t)tickets;
+        *a.queue_base = qsel ^ 1u;
         *a.queue_valid = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), FFT_LDS_BYTES, a.stream,
                        reinterpret_cast<const f2v *>(a.in), reinterpret_cast<f2v *>(a.out),
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist), a.T, a.N,
-                       n0_rate, m_rate, nblocks, (int32_t)(wgs * FFT_WAVES), (int32_t)RA, (int32_t)nA, (int32_t)RB, (int32_t)nB,
-                       (unsigned int *)a.queue,
+                       n0_rate, m_rate, nblocks, (unsigned int *)a.queue,
                        (unsigned long long *)a.dbg, (int32_t)a.diag,
                        DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a), DECN ? 0u - a.nco_word : nco_delta(a),
-                       a.chan ? *a.chan : ChanArgs{}, base, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M);
+                       a.chan ? *a.chan : ChanArgs{}, qsel, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M);
     const hipError_t le = hipGetLastError();
-    if ((le != hipSuccess || (a.diag & 32)) && a.queue_valid)
-        *a.queue_valid = false; // nothing ran (or the static diagnostic mapping): the counter did not advance as planned
+    if (le != hipSuccess && a.queue_valid)
+        *a.queue_valid = false; // nothing ran: the counters are in an unknown state
     return le;
 }
 

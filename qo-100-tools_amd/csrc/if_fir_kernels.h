@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 namespace if_fir
 {
 
@@ -50,9 +52,8 @@ struct LaunchArgs
     uint32_t nco_abs0; // absolute index (mod 2^32) of this call's input sample 0
     void *hist_out;       // device or nullptr: next history buffer (ping-pong) for the overlap-save kernel to write
                           // itself; nullptr = the caller runs launch_history (all other backends, or no outputs)
-    uint32_t *queue_base; // host: tickets handed out so far from `queue` by overlap-save launches (the counter is not
-    bool *queue_valid;    //       re-zeroed between them); *queue_valid = false after anybody else touched the counter
-    uint32_t queue_seed;  // test hook: (re)start the ticket counter and the base at this value (0 = start from zero)
+    uint32_t *queue_base; // host: which of the two counters in `queue` the next overlap-save launch draws from (each
+    bool *queue_valid;    //       launch zeroes the other one); *queue_valid = false after anybody else touched them
     const ChanArgs *chan; // filter-bank launch (overlap-save backend, D = 4): `out` is unused, outputs go to chan->out[]
 };
 
@@ -72,6 +73,38 @@ __device__ __forceinline__ float2 nco_phasor(uint32_t ph)
 }
 #endif
 
+// One-time per-(kernel, device) launcher setup (dynamic-LDS attribute, CU count), safe when distinct contexts launch
+// from distinct threads (include/if_fir.h promises that) and indexed by the real device id.
+constexpr int MAX_DEVICES = 64;
+struct DeviceSetup
+{
+    std::mutex mu;
+    bool done[MAX_DEVICES] = {};
+    int cus[MAX_DEVICES] = {};
+};
+// `kern` gets its dynamic-LDS limit raised to lds_bytes once per device; *cus (optional) = CU count of the device
+inline hipError_t device_setup(DeviceSetup &d, int device, const void *kern, int lds_bytes, int *cus)
+{
+    if (device < 0 || device >= MAX_DEVICES)
+        return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(d.mu);
+    if (!d.done[device])
+    {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess)
+            return e;
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess)
+            return e;
+        d.cus[device] = prop.multiProcessorCount;
+        d.done[device] = true;
+    }
+    if (cus)
+        *cus = d.cus[device];
+    return hipSuccess;
+}
+
 bool direct_supported(int T, int D);
 hipError_t launch_fir(const LaunchArgs &a, int variant);
 // overlap-save FFT backend (if_fir_fft.hip)
@@ -79,7 +112,7 @@ constexpr int FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024 + 64); // 
 bool fft_supported(int T, int D);
 struct FftSchedule
 {
-    int64_t RA, nA, RB, nB, tickets, wgs;
+    int64_t RA, nA, RB, nB, tickets, wgs; // blocks per group, groups, static groups per workgroup, 0, ticket bound, workgroups
 };
 void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s); // host-only: run-queue layout of a launch
 hipError_t launch_fft(const LaunchArgs &a);

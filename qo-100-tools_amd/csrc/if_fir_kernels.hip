@@ -680,15 +680,11 @@ static hipError_t launch_direct(const LaunchArgs &a)
 {
     using G = Geo<T, D, R, BLOCK>;
     auto kern = fir_direct_kernel<T, D, R, SEG, BLOCK, LDS_OUT>;
-    static bool attr_done[16] = {false};
-    const int dev = a.device & 15;
-    if (!attr_done[dev])
+    static DeviceSetup setup;
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        const hipError_t e = device_setup(setup, a.device, reinterpret_cast<const void *>(kern), G::LDS_BYTES, nullptr);
         if (e != hipSuccess)
             return e;
-        attr_done[dev] = true;
     }
     const int64_t tiles = (a.M + G::TILE_OUT - 1) / G::TILE_OUT;
     if (tiles <= 0)
@@ -710,26 +706,17 @@ static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
     static_assert(BPC >= 1, "window too large");
     constexpr int WPS = BPC >= 2 ? 2 : 1;                   // waves per SIMD the register budget is sized for
     auto kern = fir_direct_wave_kernel<T, D, R, SEG, V, WPS>;
-    static bool attr_done[16] = {false};
-    static int cus[16] = {0};
-    const int dev = a.device & 15;
-    if (!attr_done[dev])
+    static DeviceSetup setup;
+    int ncus = 0;
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        const hipError_t e = device_setup(setup, a.device, reinterpret_cast<const void *>(kern), LDS, &ncus);
         if (e != hipSuccess)
             return e;
-        hipDeviceProp_t prop;
-        e = hipGetDeviceProperties(&prop, a.device);
-        if (e != hipSuccess)
-            return e;
-        cus[dev] = prop.multiProcessorCount;
-        attr_done[dev] = true;
     }
     const int64_t tiles = (a.M + G::TILE_OUT - 1) / G::TILE_OUT;
     if (tiles <= 0)
         return hipSuccess;
-    int64_t blocks = (int64_t)cus[dev] * (BPC > 2 ? 2 : BPC);
+    int64_t blocks = (int64_t)ncus * (BPC > 2 ? 2 : BPC);
     int64_t waves = blocks * 4;
     int64_t run_len = run_len_arg > 0 ? run_len_arg : 4;
     const int64_t per_wave = (tiles + waves - 1) / waves;
@@ -827,15 +814,11 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
         if (lds > TS_MAX_LDS)
             return hipErrorInvalidConfiguration;
         auto kern = fir_tapsplit_kernel<32>;
-        static bool attr_done[16] = {false};
-        const int dev = a.device & 15;
-        if (!attr_done[dev])
+        static DeviceSetup setup;
         {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, TS_MAX_LDS);
+            const hipError_t e = device_setup(setup, a.device, reinterpret_cast<const void *>(kern), TS_MAX_LDS, nullptr);
             if (e != hipSuccess)
                 return e;
-            attr_done[dev] = true;
         }
         const int64_t blocks = (a.M + tile - 1) / tile;
         if (blocks > 0x7fffffffLL)

@@ -44,8 +44,8 @@ struct if_fir_ctx
     float *h_eff; // NCO on: effective complex taps g[k] = h[k] e^{+j theta k} (2T floats), else nullptr
     void *d_fft_tables; // overlap-save backend tables (built on first use)
     void *d_queue; // atomic run queue of the persistent kernels
-    uint32_t queue_base; // overlap-save launches let the counter run on: tickets handed out so far ...
-    bool queue_valid;    // ... valid while nobody else (direct kernel, memset) touched the counter
+    uint32_t queue_base; // overlap-save launches alternate between two counters: the one the next launch draws from ...
+    bool queue_valid;    // ... valid while nobody else (direct kernel, memset) touched the queue words
     void *d_dbg; // diagnostic wave stamps (if_fir_debug_stamps)
     void *d_power; // one float64 accumulator (if_fir_power_device)
     char info[128];
@@ -472,12 +472,6 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     }
     a.queue_base = &ctx->queue_base;
     a.queue_valid = &ctx->queue_valid;
-    if (fft_var && ctx->variant == 3000) // test hook: restart the run-queue counter 48 tickets below 2^32, once
-    {
-        a.queue_seed = 0xFFFFFFD0u;
-        ctx->queue_valid = false;
-        ctx->variant = 0;
-    }
     // the overlap-save kernel updates the history itself (one launch per call) whenever it is launched at all
     const bool fused_history = ctx->backend == IF_FIR_BACKEND_HIP_FFT && m > 0 && ctx->T > 1;
     a.hist_out = fused_history ? ctx->d_hist[ctx->hist_cur ^ 1] : nullptr;
@@ -590,10 +584,19 @@ IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float
         return 0;
     }
     HIP_TRY(pCtx, hipSetDevice(pCtx->device));
-    if (!pCtx->d_stage_in)
+    if (!pCtx->d_stage_in || !pCtx->d_stage_out)
     {
-        HIP_TRY(pCtx, hipMalloc(&pCtx->d_stage_in, 8 * pCtx->max_samples));
-        HIP_TRY(pCtx, hipMalloc(&pCtx->d_stage_out, 8 * (pCtx->max_samples / pCtx->D + 1)));
+        // both or neither: a context left with one buffer would hand a null pointer to the kernels on the next call
+        void *si = nullptr, *so = nullptr;
+        HIP_TRY(pCtx, hipMalloc(&si, 8 * pCtx->max_samples));
+        const hipError_t e2 = hipMalloc(&so, 8 * (pCtx->max_samples / pCtx->D + 1));
+        if (e2 != hipSuccess)
+        {
+            (void)hipFree(si);
+            HIP_TRY(pCtx, e2);
+        }
+        pCtx->d_stage_in = si;
+        pCtx->d_stage_out = so;
     }
     const uint64_t isz = pCtx->in_i16 ? 4 : 8;
     // Long inputs: chunks of ~2^22 samples flow through three streams (copy in, kernels, copy out), so the transfer of
@@ -681,8 +684,9 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
 }
 
-// Host-only: the run-queue layout the overlap-save launcher would use for nblocks blocks on at most ulWorkgroups
-// workgroups; pllOut receives RA, nA, RB, nB, tickets, workgroups.  The CPU tests check that the tickets tile the blocks.
+// Host-only: the block-queue layout the overlap-save launcher would use for nblocks blocks on at most ulWorkgroups
+// workgroups; pllOut receives blocks per group, groups, static groups per workgroup, 0, ticket bound, workgroups.  The
+// CPU tests replay the queue under random interleavings and check that every block is handed out exactly once.
 IF_FIR_API uint8_t if_fir_debug_fft_schedule(uint64_t ullBlocks, uint32_t ulWorkgroups, int64_t *pllOut)
 {
     if (!pllOut || !ullBlocks || !ulWorkgroups)

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 
+#include "if_fir_kernels.h"
 #include "wb_detect.h"
 
 #define WB_API extern "C" __attribute__((visibility("default")))
@@ -368,17 +369,12 @@ WB_API uint8_t wb_detect_frames_device(const uint16_t *pusDevBins, uint32_t ulFr
     if (per_wg >= 8)
     {
         const size_t lds = (size_t)per_wg * stride * sizeof(uint16_t) + WB_EVENT_BYTES; // rows (8-byte multiple) + lists
-        static bool attr_done[16] = {false};
-        if (!attr_done[lDevice & 15])
+        static if_fir::DeviceSetup setup; // once per device, safe from several threads
+        e = if_fir::device_setup(setup, (int)lDevice, reinterpret_cast<const void *>(wb_detect_kernel), WB_LDS_BYTES, nullptr);
+        if (e != hipSuccess)
         {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(wb_detect_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, WB_LDS_BYTES);
-            if (e != hipSuccess)
-            {
-                wb_err("wb_detect_frames_device: %s", hipGetErrorString(e));
-                return 0;
-            }
-            attr_done[lDevice & 15] = true;
+            wb_err("wb_detect_frames_device: %s", hipGetErrorString(e));
+            return 0;
         }
         const uint32_t wgs = (ulFrames + per_wg - 1) / per_wg;
         hipLaunchKernelGGL(wb_detect_kernel, dim3(wgs), dim3(WB_LANES * WB_WAVES), lds, stream, pusDevBins, ulFrames, ulBins, per_wg,

@@ -359,7 +359,8 @@ def debug_fft_tables(taps, decimation, complex_taps=False, nco_delta=0):
 
 
 def debug_fft_schedule(nblocks, workgroups=256):
-    """if_fir_debug_fft_schedule(): dict(RA, nA, RB, nB, tickets, wgs) of an overlap-save launch (host-only)."""
+    """if_fir_debug_fft_schedule(): block-queue layout of an overlap-save launch (host-only): RA = blocks per group,
+    nA = groups, RB = static groups per workgroup, nB = 0, tickets = bound of the global counter, wgs = workgroups."""
     out = (ctypes.c_int64 * 6)()
     if not lib().if_fir_debug_fft_schedule(int(nblocks), int(workgroups), out):
         raise IfFirError("if_fir_debug_fft_schedule: bad arguments")

@@ -869,24 +869,34 @@ def test_stream_capture_is_refused(fir, oracle, torch_cuda):
         assert l2 <= TOL and mx <= TOL
 
 
-def test_run_queue_counter_wraps(fir, oracle):
-    """The overlap-save launches let the 32-bit ticket counter run on and subtract a host-side base.  Tuning 3000 restarts
-    counter and base 48 tickets below 2^32, so the next launches cross the wrap: same numbers as from a fresh context."""
+def test_block_queue_counters_alternate_over_many_launches(fir, oracle):
+    """Overlap-save launches draw block groups from one of two global counters and zero the other one for the launch
+    behind them.  Many back-to-back calls on small grids (most blocks then come through the global counter) give the
+    same numbers as a fresh context that sees the stream in one call, also after another backend used the queue words."""
     n = 700_001
     taps = fir.bpf_design(255)
     x = oracle.synth_iq(n, 71)
-    cuts = [0, 250_000, 500_003, n]
+    cuts = [0, 100_000, 250_000, 250_004, 400_001, 500_003, 650_000, n]
     with fir.IfFir(taps, 4, n) as f:
         assert f.get_backend() == fir.BACKEND_HIP_FFT
+        # (the same cuts everywhere: where a block starts decides the last bits of an FFT result)
         ref = np.concatenate([f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
-        for grid in (0, 2002):
+        for grid in (2001, 2002, 2005, 0):
             f.reset()
-            f.set_tuning(3000)                     # consumed by the next launch
-            parts = []
-            for a, b in zip(cuts[:-1], cuts[1:]):
-                parts.append(f.process(x[2 * a:2 * b]))
-                f.set_tuning(grid)                 # a small grid draws many more tickets per launch
+            f.set_tuning(grid)
+            parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
             assert np.array_equal(np.concatenate(parts), ref), grid
+        f.set_tuning(2003)
+        f.reset()
+        first = f.process(x[:2 * 300_000])
+        f.set_backend(fir.BACKEND_HIP_DIRECT)      # the direct kernel re-zeroes and uses the same queue words
+        f.process(x[:2 * 100_000])
+        f.set_backend(fir.BACKEND_HIP_FFT)
+        f.reset()
+        again = np.concatenate([f.process(x[:2 * 300_000]), f.process(x[2 * 300_000:])])
+        assert np.array_equal(again[:first.size], first)
+        l2, mx = oracle.err_metrics(again, oracle.fir_f64(taps, x, 4))
+        assert l2 <= TOL and mx <= TOL
     l2, mx = oracle.err_metrics(ref, oracle.fir_f64(taps, x, 4))
     assert l2 <= TOL and mx <= TOL
 

@@ -177,38 +177,43 @@ def test_overlap_save_tables_refuse_unsupported(fir):
         fir.debug_fft_tables(np.ones(3075, np.float32), 1)
 
 
-def test_overlap_save_run_queue_schedule_tiles_the_blocks(fir):
-    """The guided schedule of the overlap-save launcher (host logic): ticket q is the block range the kernel's run_range()
-    derives from (RA, nA, RB, nB); over q = 0 .. tickets-1 the ranges must tile [0, nblocks) exactly once, ticket
-    `tickets` and beyond must be empty (that is how a wave learns it is done, and why a launch consumes exactly
-    `tickets` counter increments), and no more workgroups are launched than there are tickets for their waves."""
-    def run_range(q, s, nblocks):        # mirror of the device lambda in fir_fft_kernel
-        if q < s["nA"]:
-            b0, b1 = q * s["RA"], q * s["RA"] + s["RA"]
-        elif q < s["nA"] + s["nB"]:
-            b0 = s["nA"] * s["RA"] + (q - s["nA"]) * s["RB"]
-            b1 = b0 + s["RB"]
-        else:
-            b0 = s["nA"] * s["RA"] + s["nB"] * s["RB"] + (q - s["nA"] - s["nB"])
-            b1 = b0 + 1
-        return b0, min(b1, nblocks)
-
+def test_overlap_save_block_queue_hands_out_every_block_once(fir):
+    """The two-level block queue of the overlap-save kernel (host mirror of queue_take() in if_fir_fft.hip): a workgroup's
+    slot s is block s % 8 of its local group s // 8; local groups 0 and 1 are the static global groups b and wgs + b,
+    local group g >= 2 is global group 2 * wgs + ticket, the ticket drawn from the launch's counter by whoever takes
+    slot 0 of local group g - 2.  Whatever the interleaving of the workgroups' takes, every block in [0, nblocks) is
+    handed out exactly once, a wave stops at its first block >= nblocks, and the counter stays below the bound the
+    launcher reports."""
     rng = np.random.default_rng(5)
-    sizes = [1, 2, 7, 8, 9, 63, 64, 65, 2047, 2048, 2049, 4369, 8191, 16384, 17477, 69870, 69871, 139810, 1 << 20]
-    sizes += [int(v) for v in rng.integers(1, 300_000, size=40)]
+    sizes = [1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 2047, 2048, 2049, 4369, 8191, 17477, 69871]
+    sizes += [int(v) for v in rng.integers(1, 40_000, size=12)]
     for nblocks in sizes:
-        for wgs in (1, 2, 3, 8, 256, 304):
-            s = fir.debug_fft_schedule(nblocks, wgs)
-            assert 1 <= s["RA"] <= 8 and s["RB"] in (1, 2) and s["nA"] >= 0 and s["nB"] >= 0
-            assert 1 <= s["wgs"] <= wgs and (s["wgs"] - 1) * 8 < s["tickets"]
-            nxt = 0
-            for q in range(s["tickets"]):
-                b0, b1 = run_range(q, s, nblocks)
-                assert b0 == nxt and b1 > b0, (nblocks, wgs, q, b0, b1, s)
-                nxt = b1
-            assert nxt == nblocks, (nblocks, wgs, s)
-            for q in (s["tickets"], s["tickets"] + 1, s["tickets"] + 5000):
-                assert run_range(q, s, nblocks)[0] >= nblocks
+        for wgs_max in (1, 2, 3, 8, 256, 304):
+            s = fir.debug_fft_schedule(nblocks, wgs_max)
+            assert s["RA"] == 8 and s["nA"] == (nblocks + 7) // 8 and s["RB"] == 2
+            wgs = s["wgs"]
+            assert 1 <= wgs <= wgs_max and wgs <= s["nA"]
+            counter = 0
+            seen = np.zeros(nblocks, dtype=np.int32)
+            slots = [0] * wgs                       # LDS slot counter per workgroup
+            ring = [{0: b, 1: wgs + b} for b in range(wgs)]
+            live = [8] * wgs                        # waves still running per workgroup
+            order = list(range(wgs))
+            while any(live):
+                b = int(rng.choice([w for w in order if live[w]]))
+                sl = slots[b]
+                slots[b] += 1
+                g, j = divmod(sl, 8)
+                if j == 0:
+                    ring[b][g + 2] = 2 * wgs + counter
+                    counter += 1
+                blk = ring[b][g] * 8 + j
+                if blk >= nblocks:
+                    live[b] -= 1                    # this wave is done
+                else:
+                    seen[blk] += 1
+            assert (seen == 1).all(), (nblocks, wgs_max)
+            assert counter <= s["tickets"], (nblocks, wgs_max, counter, s)
 
 
 def test_bench_line_contract_on_the_committed_run():
