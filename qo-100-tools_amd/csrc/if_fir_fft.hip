@@ -234,15 +234,20 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
     void *q = (void *)(((uint64_t)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
 }
+// Cache policy of the streams (aux bits of the buffer instructions: 2 = nt, non-temporal).  Measured on 2^28 samples
+// (profiles/r02_nt_ab.txt): nt stores help every configuration (255 taps /4: 0.502 -> 0.482 ms, the outputs are never
+// read again); nt row loads help while the overlap is small (another 0.002-0.02 ms at 4 overlap rows) and cost 3 % at
+// 16 overlap rows, where a quarter of every block is re-read by the neighbouring wave and should stay cached.
 #ifndef IF_FIR_FFT_LOAD_AUX
-#define IF_FIR_FFT_LOAD_AUX 0
+#define IF_FIR_FFT_LOAD_AUX(ovl_rows) ((ovl_rows) <= 4 ? 2 : 0)
 #endif
 #ifndef IF_FIR_FFT_STORE_AUX
-#define IF_FIR_FFT_STORE_AUX 0
+#define IF_FIR_FFT_STORE_AUX 2
 #endif
+template <int AUX = 0>
 __device__ __forceinline__ cf buf_load(srd_t rsrc, unsigned voff, unsigned soff)
 {
-    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, IF_FIR_FFT_LOAD_AUX);
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, AUX);
     return (cf){__uint_as_float(v[0]), __uint_as_float(v[1])};
 }
 // int16 IQ front-end: one dword = (I, Q) as two int16; value = int16 * 2^-15
@@ -255,13 +260,13 @@ __device__ __forceinline__ cf cvt_i16(unsigned w)
 // Row `row` of a block (sample row*64 + lane) whose descriptor starts at the block's first sample.  float32 rows land
 // in r[row]; int16 rows stay RAW (one dword) in rw[row] and are converted when pass 1 consumes them — converting at
 // the load would put a vmcnt wait right behind every prefetch.
-template <bool I16>
+template <bool I16, int AUX>
 __device__ __forceinline__ void load_row(cf (&r)[64], unsigned (&rw)[64], srd_t rsrc, int lane, int row)
 {
     if constexpr (I16)
-        rw[row] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)lane * 4u, row * 256, IF_FIR_FFT_LOAD_AUX);
+        rw[row] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)lane * 4u, row * 256, AUX);
     else
-        r[row] = buf_load(rsrc, (unsigned)lane * 8u, row * 512);
+        r[row] = buf_load<AUX>(rsrc, (unsigned)lane * 8u, row * 512);
 }
 __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned soff, cf d)
 {
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     constexpr int L = FFT_N - OVL;         // new input samples per block
     constexpr int LOUT = DEC4 ? L / 4 : L; // outputs per block
     constexpr int EARLY_GROUPS = 3;        // dec4: batches of next-block loads issued during pass 3
+    constexpr int LAUX = IF_FIR_FFT_LOAD_AUX(OVL_ROWS); // cache policy of the row loads
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int rho = 0; rho < 4; rho++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16>(r, rw, srd, lane, 4 * j + rho);
+                        load_row<I16, LAUX>(r, rw, srd, lane, 4 * j + rho);
             }
             else
             {
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     {
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16>(r, rw, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX>(r, rw, nsrd, lane, phys(i, j));
                     }
                 }
                 cf c[16];
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16>(r, rw, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX>(r, rw, nsrd, lane, phys(i, j));
                 }
                 // mix-down of the decimated output: exp(-j 2 pi slot a / 16), a = abs0 + n0 + 4 m, m = obase + 64 r + lane
                 // with obase a multiple of 4: a call constant (rot0, host) times a quarter turn per lane
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16>(r, rw, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX>(r, rw, nsrd, lane, phys(i, j));
                 }
                 }
             FFT_STAMP(5);
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16>(r, rw, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX>(r, rw, nsrd, lane, phys(i, j));
             }
             constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
             if constexpr (NCO)
@@ -823,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16>(r, rw, nsrd, lane, 4 * j + rho);
+                        load_row<I16, LAUX>(r, rw, nsrd, lane, 4 * j + rho);
                 }
                 }
         }
