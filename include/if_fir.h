@@ -168,8 +168,10 @@ uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_t ulChannel
 /* ---- multi-channel front (BUILD-DEFINED, the reference has no filter surface) -------------------
  * One process per GPU.  Channel c is filtered by rank if_fir_mc_owner(c, world) = c mod world with its own taps and
  * its own streaming state.  The channel inputs and outputs live on rank 0's GPU; if_fir_mc_process_device() is called
- * by EVERY rank with the same ullSamples and moves them itself: one grouped batch of RCCL sends root -> owners, the
- * filters, one grouped batch owners -> root.  With ulWorld == 1 nothing is moved and librccl is never loaded.
+ * by EVERY rank with the same ullSamples and moves them itself in chunks of ~2^24 samples: grouped RCCL sends root ->
+ * owners on a transfer stream, the filters of a chunk on a second stream once it has landed, its outputs owners -> root
+ * behind the next chunk's scatter; a status word per owner tells the root about a remote filter failure (nobody is left
+ * waiting).  With ulWorld == 1 nothing is moved and librccl is never loaded.
  * Bootstrap: rank 0 calls if_fir_mc_unique_id(), the host program hands the 128 bytes to the other ranks by whatever
  * means it has (MPI, a socket, torch.distributed, a file), every rank passes them to if_fir_mc_init().
  * Errors: 0 + if_fir_mc_last_error(); the context stays valid.  Not re-entrant per context. */
@@ -191,6 +193,15 @@ uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ulFormat);
  * Synchronous: returns when this rank's part (transfers and filters) has finished.  *pullOutSamples: per channel. */
 uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDevIn, void *const *ppDevOut,
                                  uint64_t ullSamples, uint64_t *pullOutSamples);
+/* chunk length of the following calls: 0 = default (16 773 120 samples), UINT64_MAX = never split, otherwise a multiple of
+ * 215 040 samples (the overlap-save blocks of a chunked call then start where those of an unchunked call start: results
+ * are bit-identical whatever the chunk).  Every rank must make the same call. */
+uint8_t if_fir_mc_set_chunk_samples(if_fir_mc_ctx_t *pCtx, uint64_t ullChunk);
+/* host-only diagnostic: the transfer plan of one rank for one call, 8 uint64 per operation {kind 0 send / 1 recv, phase
+ * 0 scatter / 1 gather / 2 status, group, peer, channel, chunk, byte offset, bytes}; returns the operation count */
+uint32_t if_fir_mc_debug_plan(uint32_t ulWorld, uint32_t ulChannels, uint32_t ulRank, uint64_t ullSamples,
+                              uint32_t ulInBytes, uint32_t ulDecimation, uint64_t ullConsumed, uint64_t ullChunk,
+                              uint64_t *pullOut, uint32_t ulMaxOps);
 /* the single-channel context behind a channel this rank owns (NULL otherwise), e.g. for if_fir_set_backend() */
 if_fir_ctx_t *if_fir_mc_channel_ctx(if_fir_mc_ctx_t *pCtx, uint32_t ulChannel);
 const char *if_fir_mc_last_error(const if_fir_mc_ctx_t *pCtx);

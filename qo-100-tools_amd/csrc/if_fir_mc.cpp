@@ -1,7 +1,10 @@
 // if_fir_mc.cpp — multi-channel front of the C-ABI (include/if_fir.h, if_fir_mc_*): channel c is filtered by rank
-// c mod world, one process per GPU.  When the channel inputs live on rank 0 the library moves them itself: one grouped
-// batch of RCCL point-to-point sends (root -> owners) before the filters and one (owners -> root) after them, so the
-// root drives its xGMI links concurrently.  No reduction, no collective in the filtering itself.
+// c mod world, one process per GPU.  When the channel inputs live on rank 0 the library moves them itself, in CHUNKS of
+// ~2^24 samples: grouped RCCL point-to-point sends root -> owners (the root drives all its xGMI links at once) on a
+// transfer stream, the filters of a chunk on a second stream as soon as that chunk has landed, the chunk's outputs back
+// to the root behind the next chunk's scatter.  The transfer plan is a pure host function (mc_plan, exported for the
+// CPU tests as if_fir_mc_debug_plan): what every rank sends and receives, in which group, in which order.  No
+// reduction, no collective in the filtering itself.
 //
 // BUILD-DEFINED: the reference has no multi-channel (or any) filter surface.  librccl is opened with
 // dlopen() on first use, so single-GPU users of libif_fir.so do not load it.
@@ -28,6 +31,7 @@ struct RcclApi
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -75,11 +79,16 @@ RcclApi *rccl()
     IF_FIR_SYM(GroupEnd, "ncclGroupEnd");
     IF_FIR_SYM(GetErrorString, "ncclGetErrorString");
 #undef IF_FIR_SYM
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(lib, "ncclCommAbort"));
     g_rccl.lib = lib;
     return &g_rccl;
 }
 
 thread_local char g_mc_init_err[256] = "";
+
+// chunks of a call: multiples of the lcm of the overlap-save block advances (see the transfer plan below)
+constexpr uint64_t MC_CHUNK_UNIT = 215040;
+constexpr uint64_t MC_CHUNK_DEFAULT = 78 * MC_CHUNK_UNIT; // 16 773 120 samples, ~2^24
 } // namespace
 
 struct if_fir_mc_ctx
@@ -87,8 +96,13 @@ struct if_fir_mc_ctx
     uint32_t channels = 0, taps = 0, decim = 0, rank = 0, world = 1;
     uint32_t in_bytes = 8; // bytes per input sample (8 = float32 I,Q; 4 = int16 I,Q)
     uint64_t max_samples = 0;
+    uint64_t consumed = 0;      // samples per channel since init/reset (every rank counts: sizes of the gather pieces)
+    uint64_t chunk_samples = 0; // transfer/filter chunk (multiple of MC_CHUNK_UNIT), 0 = whole call in one piece
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // filters
+    hipStream_t xfer_stream = nullptr; // RCCL transfers
+    uint32_t *d_status = nullptr;      // device: [0] this rank's status word, [1 + r] = rank r's as received by the root
+    bool comm_broken = false;
     std::vector<if_fir_ctx_t *> fir; // per channel; nullptr for channels other ranks own
     std::vector<void *> stage_in, stage_out; // owned channels of non-root ranks
     RcclApi *api = nullptr;
@@ -163,6 +177,8 @@ static void mc_free(if_fir_mc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->xfer_stream)
+        (void)hipStreamSynchronize(ctx->xfer_stream);
     for (if_fir_ctx_t *f : ctx->fir)
         if (f)
             if_fir_destroy(f);
@@ -174,6 +190,10 @@ static void mc_free(if_fir_mc_ctx *ctx)
             (void)hipFree(p);
     if (ctx->comm)
         (void)ctx->api->CommDestroy(ctx->comm);
+    if (ctx->d_status)
+        (void)hipFree(ctx->d_status);
+    if (ctx->xfer_stream)
+        (void)hipStreamDestroy(ctx->xfer_stream);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -223,8 +243,15 @@ IF_FIR_API uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, 
     hipError_t e = hipSetDevice(lDevice);
     if (e == hipSuccess)
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && ulWorld > 1)
+        e = hipStreamCreateWithFlags(&ctx->xfer_stream, hipStreamNonBlocking);
+    if (e == hipSuccess && ulWorld > 1)
+        e = hipMalloc(reinterpret_cast<void **>(&ctx->d_status), (size_t)(1 + ulWorld) * 4);
+    if (e == hipSuccess && ulWorld > 1)
+        e = hipMemset(ctx->d_status, 0, (size_t)(1 + ulWorld) * 4);
     if (e != hipSuccess)
         MC_INIT_FAIL("if_fir_mc_init: device %d: %s", lDevice, hipGetErrorString(e));
+    ctx->chunk_samples = MC_CHUNK_DEFAULT;
     for (uint32_t c = 0; c < ulChannels; c++)
     {
         if (if_fir_mc_owner(c, ulWorld) != ulRank)
@@ -289,6 +316,7 @@ IF_FIR_API uint8_t if_fir_mc_reset(if_fir_mc_ctx_t *pCtx)
             mc_err(pCtx, "channel %u: %s", c, if_fir_last_error(pCtx->fir[c]));
             return 0;
         }
+    pCtx->consumed = 0;
     return 1;
 }
 
@@ -311,6 +339,147 @@ IF_FIR_API uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ul
     return 1;
 }
 
+// ---- transfer plan (pure host logic) ----------------------------------------------------------------------------
+// A call moves `samples` input samples per channel in chunks.  Chunk k of a call: every remote channel's input piece
+// root -> owner (scatter group k), the owners filter it, the output piece owner -> root (gather group k).  Order of
+// the groups on every rank's transfer stream: S0, S1, G0, S2, G1, ..., S(n-1), G(n-2), G(n-1), STATUS: the scatter of
+// the next chunk is queued ahead of the gather of this one, so the links stay busy while the owners filter.  Inside a
+// group the operations between a pair of ranks are posted in channel order on both sides (RCCL matches them in order).
+// STATUS: every rank that owns a channel sends one 4-byte word (0 = its filters succeeded) to the root.
+// A chunk is a multiple of MC_CHUNK_UNIT = lcm of the overlap-save block advances (3840, 3584, 3072, 2048, 1024) so
+// that the blocks of a chunked call start at the same stream positions as those of an unchunked one: bit-identical.
+
+enum : uint32_t
+{
+    MC_SEND = 0,
+    MC_RECV = 1,
+    MC_PHASE_SCATTER = 0,
+    MC_PHASE_GATHER = 1,
+    MC_PHASE_STATUS = 2
+};
+struct McXfer
+{
+    uint32_t kind, phase, group, peer, channel, chunk;
+    uint64_t offset, bytes; // byte offset inside the channel's input (scatter) or output (gather) buffer
+};
+struct McChunk
+{
+    uint64_t in_first, in_count, out_first, out_count; // samples
+};
+
+static uint64_t mc_out_count(uint64_t consumed, uint64_t n, uint32_t d)
+{
+    const uint64_t n0 = (d - consumed % d) % d;
+    return n > n0 ? (n - n0 + d - 1) / d : 0;
+}
+
+static void mc_chunks(uint64_t samples, uint64_t chunk, uint64_t consumed, uint32_t decim, std::vector<McChunk> &out)
+{
+    out.clear();
+    uint64_t done = 0, outs = 0;
+    while (done < samples)
+    {
+        const uint64_t n = (chunk && samples - done > chunk) ? chunk : samples - done;
+        const uint64_t m = mc_out_count(consumed + done, n, decim);
+        out.push_back({done, n, outs, m});
+        done += n;
+        outs += m;
+    }
+}
+
+// every transfer operation of `rank` for one call, in the order it posts them
+static void mc_plan(uint32_t world, uint32_t channels, uint32_t rank, const std::vector<McChunk> &chunks, uint32_t in_bytes,
+                    std::vector<McXfer> &ops)
+{
+    ops.clear();
+    if (world < 2 || chunks.empty())
+        return;
+    const uint32_t n = (uint32_t)chunks.size();
+    uint32_t group = 0;
+    auto scatter = [&](uint32_t k) {
+        for (uint32_t c = 0; c < channels; c++)
+        {
+            const uint32_t owner = c % world;
+            if (owner == 0 || !chunks[k].in_count)
+                continue;
+            if (rank == 0)
+                ops.push_back({MC_SEND, MC_PHASE_SCATTER, group, owner, c, k, chunks[k].in_first * in_bytes, chunks[k].in_count * in_bytes});
+            else if (rank == owner)
+                ops.push_back({MC_RECV, MC_PHASE_SCATTER, group, 0, c, k, chunks[k].in_first * in_bytes, chunks[k].in_count * in_bytes});
+        }
+        group++;
+    };
+    auto gather = [&](uint32_t k) {
+        for (uint32_t c = 0; c < channels; c++)
+        {
+            const uint32_t owner = c % world;
+            if (owner == 0 || !chunks[k].out_count)
+                continue;
+            if (rank == 0)
+                ops.push_back({MC_RECV, MC_PHASE_GATHER, group, owner, c, k, chunks[k].out_first * 8, chunks[k].out_count * 8});
+            else if (rank == owner)
+                ops.push_back({MC_SEND, MC_PHASE_GATHER, group, 0, c, k, chunks[k].out_first * 8, chunks[k].out_count * 8});
+        }
+        group++;
+    };
+    scatter(0);
+    for (uint32_t k = 1; k < n; k++)
+    {
+        scatter(k);
+        gather(k - 1);
+    }
+    gather(n - 1);
+    for (uint32_t r = 1; r < world && r < channels; r++) // ranks 1 .. min(world, channels) - 1 own at least one channel
+    {
+        if (rank == 0)
+            ops.push_back({MC_RECV, MC_PHASE_STATUS, group, r, 0, 0, (uint64_t)(1 + r) * 4, 4});
+        else if (rank == r)
+            ops.push_back({MC_SEND, MC_PHASE_STATUS, group, 0, 0, 0, 0, 4});
+    }
+}
+
+// Host-only: the transfer plan of one rank as 8 uint64 per operation {kind, phase, group, peer, channel, chunk, offset,
+// bytes}; returns the number of operations (also when pullOut is too small or NULL).  ullChunk = 0: one piece.
+IF_FIR_API uint32_t if_fir_mc_debug_plan(uint32_t ulWorld, uint32_t ulChannels, uint32_t ulRank, uint64_t ullSamples,
+                                         uint32_t ulInBytes, uint32_t ulDecimation, uint64_t ullConsumed, uint64_t ullChunk,
+                                         uint64_t *pullOut, uint32_t ulMaxOps)
+{
+    if (!ulWorld || !ulChannels || ulRank >= ulWorld || !ulDecimation || (ulInBytes != 4 && ulInBytes != 8))
+        return 0;
+    std::vector<McChunk> chunks;
+    mc_chunks(ullSamples, ullChunk, ullConsumed, ulDecimation, chunks);
+    std::vector<McXfer> ops;
+    mc_plan(ulWorld, ulChannels, ulRank, chunks, ulInBytes, ops);
+    for (size_t i = 0; pullOut && i < ops.size() && i < ulMaxOps; i++)
+    {
+        const McXfer &o = ops[i];
+        const uint64_t row[8] = {o.kind, o.phase, o.group, o.peer, o.channel, o.chunk, o.offset, o.bytes};
+        memcpy(pullOut + 8 * i, row, sizeof(row));
+    }
+    return (uint32_t)ops.size();
+}
+
+// chunk length of the calls that follow: 0 = default (~2^24 samples), otherwise a multiple of 215040 samples (see above);
+// UINT64_MAX = never split.  Every rank must make the same call.
+IF_FIR_API uint8_t if_fir_mc_set_chunk_samples(if_fir_mc_ctx_t *pCtx, uint64_t ullChunk)
+{
+    if (!pCtx)
+        return 0;
+    if (ullChunk == UINT64_MAX)
+        pCtx->chunk_samples = 0;
+    else if (ullChunk == 0)
+        pCtx->chunk_samples = MC_CHUNK_DEFAULT;
+    else if (ullChunk % MC_CHUNK_UNIT)
+    {
+        mc_err(pCtx, "if_fir_mc_set_chunk_samples: %llu is not a multiple of %llu samples", (unsigned long long)ullChunk,
+               (unsigned long long)MC_CHUNK_UNIT);
+        return 0;
+    }
+    else
+        pCtx->chunk_samples = ullChunk;
+    return 1;
+}
+
 IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDevIn, void *const *ppDevOut,
                                             uint64_t ullSamples, uint64_t *pullOutSamples)
 {
@@ -320,6 +489,11 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
     const bool root = ctx->rank == 0;
     if (pullOutSamples)
         *pullOutSamples = 0;
+    if (ctx->comm_broken)
+    {
+        mc_err(ctx, "if_fir_mc_process_device: the communicator was aborted after an earlier RCCL failure; create a new context");
+        return 0;
+    }
     if (ullSamples > ctx->max_samples)
     {
         mc_err(ctx, "if_fir_mc_process_device: %llu samples exceed the %llu of init", (unsigned long long)ullSamples,
@@ -339,75 +513,179 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
                 return 0;
             }
     MC_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t in_bytes = (size_t)ullSamples * ctx->in_bytes;
-    // ---- scatter: root -> owners, one group (all peers' links busy at once) ---------------------------------------
-    if (ctx->world > 1 && in_bytes)
-    {
-        MC_RCCL(ctx, ctx->api->GroupStart());
-        for (uint32_t c = 0; c < ctx->channels; c++)
+    std::vector<McChunk> chunks;
+    mc_chunks(ullSamples, ctx->chunk_samples, ctx->consumed, ctx->decim, chunks);
+    std::vector<McXfer> ops;
+    mc_plan(ctx->world, ctx->channels, ctx->rank, chunks, ctx->in_bytes, ops);
+    const uint32_t nchunks = (uint32_t)chunks.size();
+    // events: chunk k's input has landed (transfer stream -> filter stream), chunk k is filtered (filter -> transfer)
+    std::vector<hipEvent_t> ev_in(nchunks, nullptr), ev_out(nchunks, nullptr);
+    auto free_events = [&]() {
+        for (hipEvent_t e : ev_in)
+            if (e)
+                (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_out)
+            if (e)
+                (void)hipEventDestroy(e);
+    };
+    bool local_fail = false, rccl_fail = false; // a filter call failed / an RCCL call failed (text is in ctx->err)
+    size_t next_op = 0;
+    // posts every operation of the next group; a failing call does not leave the group open
+    auto post_group = [&](uint32_t group) {
+        if (next_op >= ops.size() || ops[next_op].group != group)
+            return; // nothing of this rank in this group
+        ncclResult_t first_bad = ctx->api->GroupStart();
+        bool opened = first_bad == ncclSuccess;
+        for (; next_op < ops.size() && ops[next_op].group == group; next_op++)
         {
-            const uint32_t owner = if_fir_mc_owner(c, ctx->world);
-            if (owner == 0)
+            const McXfer &o = ops[next_op];
+            if (!opened || rccl_fail)
                 continue;
-            if (root)
-                MC_RCCL(ctx, ctx->api->Send(ppDevIn[c], in_bytes, ncclUint8, (int)owner, ctx->comm, ctx->stream));
-            else if (owner == ctx->rank)
-                MC_RCCL(ctx, ctx->api->Recv(ctx->stage_in[c], in_bytes, ncclUint8, 0, ctx->comm, ctx->stream));
+            char *buf;
+            if (o.phase == MC_PHASE_STATUS)
+                buf = reinterpret_cast<char *>(ctx->d_status);
+            else if (o.phase == MC_PHASE_SCATTER)
+                buf = root ? (char *)const_cast<void *>(ppDevIn[o.channel]) : (char *)ctx->stage_in[o.channel];
+            else
+                buf = root ? (char *)ppDevOut[o.channel] : (char *)ctx->stage_out[o.channel];
+            const ncclResult_t r = o.kind == MC_SEND
+                                       ? ctx->api->Send(buf + o.offset, o.bytes, ncclUint8, (int)o.peer, ctx->comm, ctx->xfer_stream)
+                                       : ctx->api->Recv(buf + o.offset, o.bytes, ncclUint8, (int)o.peer, ctx->comm, ctx->xfer_stream);
+            if (r != ncclSuccess && first_bad == ncclSuccess)
+                first_bad = r;
         }
-        MC_RCCL(ctx, ctx->api->GroupEnd());
-    }
-    // ---- this rank's channels, back to back on the context's stream -----------------------------------------------
-    uint64_t out_samples = 0;
-    bool first = true;
-    for (uint32_t c = 0; c < ctx->channels; c++)
-    {
-        if (!ctx->fir[c])
-            continue;
-        uint64_t m = 0;
-        const void *src = root ? ppDevIn[c] : ctx->stage_in[c];
-        void *dst = root ? ppDevOut[c] : ctx->stage_out[c];
-        if (!if_fir_process_device(ctx->fir[c], src, dst, ullSamples, &m))
+        if (opened)
         {
-            mc_err(ctx, "channel %u: %s", c, if_fir_last_error(ctx->fir[c]));
-            return 0;
+            const ncclResult_t r = ctx->api->GroupEnd();
+            if (r != ncclSuccess && first_bad == ncclSuccess)
+                first_bad = r;
         }
-        if (first)
-            out_samples = m;
-        else if (m != out_samples)
+        if (first_bad != ncclSuccess && !rccl_fail)
         {
-            mc_err(ctx, "channel %u produced %llu samples, channel before %llu (streams out of step)", c,
-                   (unsigned long long)m, (unsigned long long)out_samples);
-            return 0;
+            rccl_fail = true;
+            mc_err(ctx, "RCCL transfer group %u failed: %s", group, ctx->api->GetErrorString(first_bad));
         }
-        first = false;
-    }
-    // every channel has consumed the same number of samples, so every channel produces the same count; a rank without
-    // channels (world > channels) computes it from rank-independent state
-    if (first)
-        out_samples = 0;
-    // ---- gather: owners -> root ------------------------------------------------------------------------------------
-    if (ctx->world > 1 && in_bytes)
-    {
-        // the root needs the count of the remote channels: identical to its own (channel 0 is always the root's)
-        const size_t out_bytes = (size_t)out_samples * 8;
-        if (out_bytes)
+    };
+    auto filter_chunk = [&](uint32_t k) {
+        const McChunk &ch = chunks[k];
+        for (uint32_t c = 0; c < ctx->channels && !local_fail; c++)
         {
-            MC_RCCL(ctx, ctx->api->GroupStart());
-            for (uint32_t c = 0; c < ctx->channels; c++)
+            if (!ctx->fir[c])
+                continue;
+            uint64_t m = 0;
+            const char *src = (root ? (const char *)ppDevIn[c] : (const char *)ctx->stage_in[c]) + ch.in_first * ctx->in_bytes;
+            char *dst = (root ? (char *)ppDevOut[c] : (char *)ctx->stage_out[c]) + ch.out_first * 8;
+            if (!if_fir_process_device(ctx->fir[c], src, dst, ch.in_count, &m))
             {
-                const uint32_t owner = if_fir_mc_owner(c, ctx->world);
-                if (owner == 0)
-                    continue;
-                if (root)
-                    MC_RCCL(ctx, ctx->api->Recv(ppDevOut[c], out_bytes, ncclUint8, (int)owner, ctx->comm, ctx->stream));
-                else if (owner == ctx->rank)
-                    MC_RCCL(ctx, ctx->api->Send(ctx->stage_out[c], out_bytes, ncclUint8, 0, ctx->comm, ctx->stream));
+                mc_err(ctx, "channel %u: %s", c, if_fir_last_error(ctx->fir[c]));
+                local_fail = true;
             }
-            MC_RCCL(ctx, ctx->api->GroupEnd());
+            else if (m != ch.out_count)
+            {
+                mc_err(ctx, "channel %u produced %llu samples where the plan has %llu (streams out of step)", c,
+                       (unsigned long long)m, (unsigned long long)ch.out_count);
+                local_fail = true;
+            }
+        }
+    };
+    hipError_t he = hipSuccess;
+#define MC_STEP(call)                         \
+    do                                        \
+    {                                         \
+        if (he == hipSuccess)                 \
+            he = (call);                      \
+    } while (0)
+    const bool moving = ctx->world > 1 && !ops.empty();
+    uint32_t group = 0;
+    auto scatter_step = [&](uint32_t k) {
+        if (moving)
+        {
+            post_group(group);
+            if (!root)
+            {
+                MC_STEP(hipEventCreateWithFlags(&ev_in[k], hipEventDisableTiming));
+                MC_STEP(hipEventRecord(ev_in[k], ctx->xfer_stream));
+                MC_STEP(hipStreamWaitEvent(ctx->stream, ev_in[k], 0)); // the filters of chunk k wait for its input
+            }
+        }
+        group++;
+        if (he == hipSuccess && !local_fail)
+            filter_chunk(k);
+        if (moving && !root)
+        {
+            MC_STEP(hipEventCreateWithFlags(&ev_out[k], hipEventDisableTiming));
+            MC_STEP(hipEventRecord(ev_out[k], ctx->stream));
+        }
+    };
+    auto gather_step = [&](uint32_t k) {
+        if (moving)
+        {
+            if (!root && ev_out[k])
+                MC_STEP(hipStreamWaitEvent(ctx->xfer_stream, ev_out[k], 0)); // send chunk k's outputs once they exist
+            post_group(group);
+        }
+        group++;
+    };
+    if (nchunks)
+    {
+        scatter_step(0);
+        for (uint32_t k = 1; k < nchunks; k++)
+        {
+            scatter_step(k);
+            gather_step(k - 1);
+        }
+        gather_step(nchunks - 1);
+        if (moving)
+        {
+            // status word: the protocol above is completed even after a local failure, so that no peer is left waiting;
+            // the root learns about it here
+            if (!root)
+                MC_STEP(hipMemsetD32Async((hipDeviceptr_t)ctx->d_status, local_fail ? 1 : 0, 1, ctx->xfer_stream));
+            post_group(group);
         }
     }
-    MC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#undef MC_STEP
+    hipError_t se = hipStreamSynchronize(ctx->stream);
+    if (he == hipSuccess)
+        he = se;
+    if (ctx->xfer_stream)
+    {
+        se = hipStreamSynchronize(ctx->xfer_stream);
+        if (he == hipSuccess)
+            he = se;
+    }
+    free_events();
+    if (rccl_fail)
+    {
+        // peers may be blocked in a transfer this rank never posted: abort the communicator so that they fail instead
+        if (ctx->api && ctx->api->CommAbort && ctx->comm)
+        {
+            (void)ctx->api->CommAbort(ctx->comm);
+            ctx->comm = nullptr;
+        }
+        ctx->comm_broken = true;
+        return 0;
+    }
+    if (he != hipSuccess)
+    {
+        mc_err(ctx, "if_fir_mc_process_device: %s", hipGetErrorString(he));
+        return 0;
+    }
+    if (local_fail)
+        return 0;
+    if (root && moving)
+    {
+        std::vector<uint32_t> st(1 + ctx->world, 0);
+        MC_HIP(ctx, hipMemcpy(st.data(), ctx->d_status, st.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t r = 1; r < ctx->world && r < ctx->channels; r++)
+            if (st[1 + r])
+            {
+                mc_err(ctx, "if_fir_mc_process_device: rank %u reported a filter failure (its outputs are invalid)", r);
+                return 0;
+            }
+    }
+    ctx->consumed += ullSamples;
     if (pullOutSamples)
-        *pullOutSamples = out_samples;
+        *pullOutSamples = chunks.empty() ? 0 : chunks.back().out_first + chunks.back().out_count;
     return 1;
 }

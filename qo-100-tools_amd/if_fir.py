@@ -22,6 +22,7 @@ EXPORTS = [
     "if_fir_debug_fft_tables", "if_fir_debug_fft_schedule", "if_fir_power_device",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
+    "if_fir_mc_set_chunk_samples", "if_fir_mc_debug_plan",
 ]
 MC_ID_BYTES = 128
 
@@ -128,6 +129,10 @@ def lib():
     L.if_fir_mc_channel_ctx.restype = vp
     L.if_fir_mc_last_error.argtypes = [vp]
     L.if_fir_mc_last_error.restype = ctypes.c_char_p
+    L.if_fir_mc_set_chunk_samples.argtypes = [vp, u64]
+    L.if_fir_mc_set_chunk_samples.restype = u8
+    L.if_fir_mc_debug_plan.argtypes = [u32, u32, u32, u64, u32, u32, u64, u64, ctypes.POINTER(u64), u32]
+    L.if_fir_mc_debug_plan.restype = u32
     _lib = L
     return L
 
@@ -372,6 +377,22 @@ def mc_owner(channel, world):
     return int(lib().if_fir_mc_owner(int(channel), int(world)))
 
 
+MC_CHUNK_UNIT = 215040
+MC_NEVER_SPLIT = (1 << 64) - 1
+
+
+def mc_debug_plan(world, channels, rank, samples, in_bytes=8, decimation=1, consumed=0, chunk=0):
+    """if_fir_mc_debug_plan(): list of dict(kind, phase, group, peer, channel, chunk, offset, bytes) in posting order
+    (host-only; chunk=0 means one piece here)."""
+    n = lib().if_fir_mc_debug_plan(int(world), int(channels), int(rank), int(samples), int(in_bytes), int(decimation),
+                                   int(consumed), int(chunk), None, 0)
+    buf = np.zeros(8 * max(n, 1), dtype=np.uint64)
+    lib().if_fir_mc_debug_plan(int(world), int(channels), int(rank), int(samples), int(in_bytes), int(decimation),
+                               int(consumed), int(chunk), buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n)
+    keys = ("kind", "phase", "group", "peer", "channel", "chunk", "offset", "bytes")
+    return [dict(zip(keys, (int(v) for v in buf[8 * i:8 * i + 8]))) for i in range(n)]
+
+
 def mc_unique_id():
     """if_fir_mc_unique_id(): rank 0's RCCL bootstrap id (128 bytes) to hand to the other ranks."""
     buf = (ctypes.c_uint8 * MC_ID_BYTES)()
@@ -407,6 +428,10 @@ class IfFirMc:
 
     def set_input_format(self, fmt):
         self._check(lib().if_fir_mc_set_input_format(self._ctx, int(fmt)))
+
+    def set_chunk_samples(self, chunk):
+        """0 = default chunk, MC_NEVER_SPLIT = whole calls, else a multiple of MC_CHUNK_UNIT samples."""
+        self._check(lib().if_fir_mc_set_chunk_samples(self._ctx, int(chunk)))
 
     def channel_ctx(self, channel):
         """Raw if_fir_ctx_t* (int) of a channel this rank owns, else None."""

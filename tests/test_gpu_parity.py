@@ -478,6 +478,43 @@ def test_multi_channel_front_one_rank(fir, oracle, torch_cuda):
         assert mc.process_device([p.data_ptr() for p in dev_in], [o.data_ptr() for o in outs], 64) == 16
 
 
+def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
+    """The multi-channel front moves and filters a call in chunks (multiples of 215040 samples = lcm of the overlap-save
+    block advances, so blocks start where they would in one piece).  One rank, three channels, two calls with a carried
+    phase: any chunking gives bit-identical outputs, for every overlap length and for decimations 1, 4 and 3."""
+    torch = torch_cuda
+    n = 1_000_003
+    cuts = [0, 600_002, n]
+    for t, d in ((255, 4), (1023, 1), (511, 3), (2047, 4)):
+        taps = np.stack([fir.bpf_design(t, 0.15, 0.25), fir.bpf_design(t, 0.02, 0.08), fir.bpf_design(t, 0.3, 0.45)])
+        dev_in = [torch.from_numpy(oracle.synth_iq(n, 40 + c)).cuda() for c in range(3)]
+        results = {}
+        with fir.IfFirMc(taps, d, n) as mc:
+            with pytest.raises(fir.IfFirError, match="multiple"):
+                mc.set_chunk_samples(100_000)
+            for chunk in (fir.MC_NEVER_SPLIT, fir.MC_CHUNK_UNIT, 2 * fir.MC_CHUNK_UNIT, 0):
+                mc.set_chunk_samples(chunk)
+                mc.reset()
+                parts = [[] for _ in range(3)]
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    m_exp = oracle.out_count(a, b - a, d)
+                    outs = [torch.full((2 * m_exp + 8,), 7.0, dtype=torch.float32, device="cuda") for _ in range(3)]
+                    pieces = [x[2 * a:2 * b].clone() for x in dev_in]
+                    torch.cuda.synchronize()
+                    assert mc.process_device([p.data_ptr() for p in pieces], [o.data_ptr() for o in outs], b - a) == m_exp
+                    for c in range(3):
+                        o = outs[c].cpu().numpy()
+                        assert np.all(o[2 * m_exp:] == 7.0)
+                        parts[c].append(o[:2 * m_exp])
+                results[chunk] = [np.concatenate(p) for p in parts]
+        ref = results[fir.MC_NEVER_SPLIT]
+        for chunk, res in results.items():
+            for c in range(3):
+                assert np.array_equal(res[c], ref[c]), (t, d, chunk, c)
+        l2, mx = oracle.err_metrics(ref[1], oracle.fir_f64(taps[1], dev_in[1].cpu().numpy(), d))
+        assert l2 <= TOL and mx <= TOL, (t, d, l2, mx)
+
+
 def test_multi_channel_bootstrap_id(fir, gpu_ok):
     """if_fir_mc_unique_id(): librccl is opened on demand and hands out a bootstrap id (the >1-rank transfers need
     more than the one GPU of this box; their rank/peer bookkeeping is the same c mod world rule the gloo tests cover)."""

@@ -1,0 +1,111 @@
+"""CPU tests of the multi-channel front's transfer plan (if_fir_mc_debug_plan, the function if_fir_mc_process_device
+executes): every send has exactly one matching receive of equal size, posted in the same group and in the same order
+between the two ranks; the bytes add up to whole channels; and a replay of all ranks' transfer streams never blocks."""
+import itertools
+
+import pytest
+
+SEND, RECV = 0, 1
+SCATTER, GATHER, STATUS = 0, 1, 2
+
+
+def all_plans(fir, world, channels, samples, in_bytes, decim, consumed, chunk):
+    return [fir.mc_debug_plan(world, channels, r, samples, in_bytes, decim, consumed, chunk) for r in range(world)]
+
+
+def out_count(consumed, n, d):
+    n0 = (d - consumed % d) % d
+    return (n - n0 + d - 1) // d if n > n0 else 0
+
+
+CASES = [(s, ch, d, cons) for s, ch, d, cons in [
+    (1, 0, 1, 0), (500_000, 215_040, 4, 0), (500_000, 215_040, 4, 3), (645_120, 215_040, 1, 0), (430_081, 215_040, 3, 7),
+    (1 << 22, 0, 4, 0), (3, 215_040, 4, 2), (1_000_000, 430_080, 8, 5)]]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+@pytest.mark.parametrize("channels", [1, 3, 8, 13])
+def test_every_send_has_one_matching_recv_in_the_same_group_order(fir, world, channels):
+    for (samples, chunk, decim, consumed), in_bytes in itertools.product(CASES, (8, 4)):
+        plans = all_plans(fir, world, channels, samples, in_bytes, decim, consumed, chunk)
+        for r, plan in enumerate(plans):
+            groups = [o["group"] for o in plan]
+            assert groups == sorted(groups), "a rank posts its groups in increasing order"
+            for o in plan:
+                assert o["peer"] != r and o["peer"] < world and o["bytes"] > 0
+                assert (o["peer"] == 0) != (r == 0), "all traffic is root <-> owner"
+        for a, b in itertools.permutations(range(world), 2):
+            sends = [o for o in plans[a] if o["kind"] == SEND and o["peer"] == b]
+            recvs = [o for o in plans[b] if o["kind"] == RECV and o["peer"] == a]
+            assert len(sends) == len(recvs), (world, channels, a, b)
+            for s, rv in zip(sends, recvs):   # RCCL matches the operations between two ranks in posting order
+                assert (s["group"], s["phase"], s["channel"], s["chunk"], s["bytes"]) == \
+                       (rv["group"], rv["phase"], rv["channel"], rv["chunk"], rv["bytes"])
+                if s["phase"] != STATUS:
+                    assert s["offset"] == rv["offset"]          # same piece of the channel on both sides
+        # volume: every remote channel's whole input goes out once, its whole output comes back once
+        root = plans[0]
+        for c in range(channels):
+            if c % world == 0:
+                assert not [o for o in root if o["channel"] == c and o["phase"] != STATUS]
+                continue
+            sc = [o for o in root if o["channel"] == c and o["phase"] == SCATTER]
+            ga = [o for o in root if o["channel"] == c and o["phase"] == GATHER]
+            assert all(o["kind"] == SEND and o["peer"] == c % world for o in sc)
+            assert all(o["kind"] == RECV and o["peer"] == c % world for o in ga)
+            assert sum(o["bytes"] for o in sc) == samples * in_bytes
+            assert sum(o["bytes"] for o in ga) == 8 * out_count(consumed, samples, decim)
+            for ops, unit in ((sc, in_bytes), (ga, 8)):     # contiguous, in order
+                pos = 0
+                for o in ops:
+                    assert o["offset"] == pos and o["bytes"] % unit == 0
+                    pos += o["bytes"]
+        owners = {c % world for c in range(channels)} - {0}
+        assert {o["peer"] for o in root if o["phase"] == STATUS} == owners
+
+
+@pytest.mark.parametrize("world,channels", [(2, 3), (3, 8), (4, 13), (8, 8), (8, 3)])
+def test_replay_of_all_ranks_never_blocks(fir, world, channels):
+    """Every rank executes its groups in order on one stream; a group completes when each of its operations has its
+    counterpart in the group the peer is currently executing.  The replay must drain every rank."""
+    for samples, chunk, decim, consumed in CASES:
+        plans = all_plans(fir, world, channels, samples, 8, decim, consumed, chunk)
+        queues = []
+        for plan in plans:
+            q = []
+            for o in plan:
+                if not q or q[-1][0]["group"] != o["group"]:
+                    q.append([])
+                q[-1].append(o)
+            queues.append(q)
+        pos = [0] * world
+
+        def current(r):
+            return queues[r][pos[r]] if pos[r] < len(queues[r]) else None
+
+        def matched(r):
+            for o in current(r):
+                peer_group = current(o["peer"])
+                if peer_group is None:
+                    return False
+                want = (1 - o["kind"], r, o["phase"], o["channel"], o["chunk"], o["bytes"])
+                if not any((p["kind"], p["peer"], p["phase"], p["channel"], p["chunk"], p["bytes"]) == want for p in peer_group):
+                    return False
+            return True
+
+        for _ in range(10_000):
+            ready = [r for r in range(world) if current(r) is not None and matched(r)]
+            if not ready:
+                break
+            # a group between two ranks completes on both at once; ranks whose whole group is matched move on
+            for r in ready:
+                pos[r] += 1
+        assert all(current(r) is None for r in range(world)), (world, channels, samples, chunk, pos)
+
+
+def test_plan_rejects_bad_arguments_and_single_rank_moves_nothing(fir):
+    assert fir.mc_debug_plan(1, 5, 0, 1 << 20) == []
+    assert fir.mc_debug_plan(4, 2, 3, 1 << 20) == []          # a rank without channels takes no part
+    assert fir.lib().if_fir_mc_debug_plan(0, 1, 0, 10, 8, 1, 0, 0, None, 0) == 0
+    assert fir.lib().if_fir_mc_debug_plan(2, 1, 2, 10, 8, 1, 0, 0, None, 0) == 0
+    assert fir.lib().if_fir_mc_debug_plan(2, 1, 0, 10, 5, 1, 0, 0, None, 0) == 0
