@@ -371,7 +371,7 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
 template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN, bool DECN>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
-                                                        int T, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
+                                                        int HL, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
                                                         unsigned int *queue, unsigned long long *dbg, int32_t diag,
                                                         uint32_t nco_phi0, uint32_t nco_delta, ChanArgs chan,
                                                         uint32_t qsel, void *__restrict__ hist_out,
@@ -414,11 +414,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     }
     __syncthreads();
     unsigned int *gqueue = queue + qsel;
-    // streaming state: the history of the NEXT call = the last T-1 samples of (history || input), written to the other
+    // streaming state: the history of the NEXT call = the last HL samples of (history || input) (HL = the block overlap,
+    // >= T-1: the first block of a call then sees the very samples an interior block sees), written to the other
     // ping-pong buffer by one wave (everything it reads is read-only in this launch); spares a launch per call
     if (hist_out && blockIdx.x == 0 && wid == 0)
     {
-        const int64_t keep = (int64_t)T - 1;
+        const int64_t keep = (int64_t)HL;
         for (int64_t i = lane; i < keep; i += 64)
         {
             const int64_t gi = N - keep + i, hi = keep + gi;
@@ -505,12 +506,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 // loads of every element is out of range and returns 0
                 // (an int16 stream keeps its history as raw int16 pairs too, so the block stays raw: OR of the two loads)
                 const srd_t srd_in = make_srd(in, N * ISZ);
-                const srd_t srd_h = make_srd(hist, (int64_t)(T - 1) * ISZ);
+                const srd_t srd_h = make_srd(hist, (int64_t)HL * ISZ);
 #pragma unroll
                 for (int row = 0; row < 64; row++)
                 {
                     const int64_t gidx = s0 + row * 64 + lane;
-                    const int64_t hidx = gidx + (T - 1);
+                    const int64_t hidx = gidx + HL;
                     const unsigned oi = (gidx >= 0) ? (unsigned)gidx * (unsigned)ISZ : 0x80000000u;
                     const unsigned oh = (gidx < 0 && hidx >= 0) ? (unsigned)hidx * (unsigned)ISZ : 0x80000000u;
                     if constexpr (I16)
@@ -909,7 +910,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), FFT_LDS_BYTES, a.stream,
                        reinterpret_cast<const f2v *>(a.in), reinterpret_cast<f2v *>(a.out),
-                       reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist), a.T, a.N,
+                       reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist_full), a.hist_len, a.N,
                        n0_rate, m_rate, nblocks, (unsigned int *)a.queue,
                        (unsigned long long *)a.dbg, (int32_t)a.diag,
                        DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a), DECN ? 0u - a.nco_word : nco_delta(a),

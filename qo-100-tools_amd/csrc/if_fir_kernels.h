@@ -33,7 +33,9 @@ struct LaunchArgs
     const void *in;    // device, interleaved float32 I/Q, N samples
     void *out;         // device, M samples
     const float *taps; // device, T floats
-    const void *hist;  // device, T-1 samples (most recent last)
+    const void *hist;  // device, the T-1 most recent samples before this call (most recent last)
+    const void *hist_full; // device, start of the whole history buffer: hist_len >= T-1 samples, most recent last (the
+    int hist_len;          // overlap-save kernel keeps a whole block overlap so that call boundaries do not show)
     int T, D;
     int in_i16; // 1: input samples are interleaved int16 I,Q (value = int16 * 2^-15); FFT and generic backends only
     int ctaps;  // 1: taps are complex (interleaved re,im), FFT and generic backends only
@@ -118,7 +120,9 @@ void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s); // host-onl
 hipError_t launch_fft(const LaunchArgs &a);
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale, float *tables);
 
-hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, int in_i16,
+int fft_overlap_rows(int T);
+// history buffers hold the last `hist_len` samples of the stream (>= T-1; hist_in/hist_out: whole buffers)
+hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int hist_len, int64_t N, int in_i16,
                           hipStream_t stream);
 hipError_t launch_power(const void *iq, uint64_t samples, double *acc, hipStream_t stream); // acc: device double
 hipError_t launch_synth(void *iq, uint64_t first, uint64_t count, uint32_t channel, const float *tone10,

@@ -618,21 +618,20 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const f2 *__restrict__
 // --------------------------------------------------------------------------------------------------------------
 template <bool I16>
 __global__ void fir_history_kernel(const f2 *__restrict__ in, const f2 *__restrict__ hist_in, f2 *__restrict__ hist_out,
-                                   int T, int64_t N)
+                                   int H, int64_t N)
 {
+    // hist_out = the last H samples of (hist_in || in), raw (int16 pairs stay int16 pairs)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T - 1)
+    if (i >= H)
         return;
-    const int64_t g = N - (int64_t)(T - 1) + i;
+    const int64_t g = N - (int64_t)H + i, h = (int64_t)H + g;
     if constexpr (I16)
     {
-        // raw copy of the int16 pairs (4 bytes per sample)
         const int *src = reinterpret_cast<const int *>(in), *hsrc = reinterpret_cast<const int *>(hist_in);
-        const int64_t h = (int64_t)(T - 1) + g;
         reinterpret_cast<int *>(hist_out)[i] = (g >= 0) ? src[g] : (h >= 0 ? hsrc[h] : 0);
     }
     else
-        hist_out[i] = fetch_sample<false>(in, hist_in, T, g, N);
+        hist_out[i] = (g >= 0) ? in[g] : (h >= 0 ? hist_in[h] : (f2){0.f, 0.f});
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -859,20 +858,20 @@ bool direct_supported(int T, int D)
     return (T == 255 || T == 127) && (D == 1 || D == 4);
 }
 
-hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int T, int64_t N, int in_i16,
+hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int hist_len, int64_t N, int in_i16,
                           hipStream_t stream)
 {
-    if (T <= 1)
+    if (hist_len < 1)
         return hipSuccess;
-    const int blocks = (T - 1 + 255) / 256;
+    const int blocks = (hist_len + 255) / 256;
     if (in_i16)
         hipLaunchKernelGGL(fir_history_kernel<true>, dim3(blocks), dim3(256), 0, stream,
                            reinterpret_cast<const f2 *>(in), reinterpret_cast<const f2 *>(hist_in),
-                           reinterpret_cast<f2 *>(hist_out), T, N);
+                           reinterpret_cast<f2 *>(hist_out), hist_len, N);
     else
         hipLaunchKernelGGL(fir_history_kernel<false>, dim3(blocks), dim3(256), 0, stream,
                            reinterpret_cast<const f2 *>(in), reinterpret_cast<const f2 *>(hist_in),
-                           reinterpret_cast<f2 *>(hist_out), T, N);
+                           reinterpret_cast<f2 *>(hist_out), hist_len, N);
     return hipGetLastError();
 }
 

@@ -29,7 +29,8 @@ struct if_fir_ctx
     uint32_t backend;
     int variant;
     float *d_taps;
-    void *d_hist[2];
+    void *d_hist[2]; // the last hist_len samples of the stream (raw input format), ping-pong
+    int hist_len;    // max(T-1, the overlap-save block overlap): see hist_len_for()
     int hist_cur;
     uint64_t consumed;
     uint64_t max_samples;
@@ -92,6 +93,19 @@ static uint32_t resolve_backend(const if_fir_ctx *ctx, uint32_t req)
     if (eff_ctaps(ctx) || ctx->in_i16)
         return IF_FIR_BACKEND_HIP_GENERIC;
     return if_fir::direct_supported(ctx->T, ctx->D) ? IF_FIR_BACKEND_HIP_DIRECT : IF_FIR_BACKEND_HIP_TAPSPLIT;
+}
+
+// History kept between calls: T-1 samples are what the filter needs; the overlap-save kernel's blocks start a whole
+// overlap (4..48 rows of 64 samples) before their first output, and keeping that many makes the first block of a call
+// identical to the interior block an unsplit call would have had there (results independent of how a stream is cut
+// into calls, as long as the cuts are multiples of the block advance: if_fir_mc_set_chunk_samples).
+static int hist_len_for(int T)
+{
+    const int need = T > 1 ? T - 1 : 0;
+    if (!if_fir::fft_supported(T, 1))
+        return need;
+    const int ovl = 64 * if_fir::fft_overlap_rows(T);
+    return ovl > need ? ovl : need;
 }
 
 static bool backend_ok(const if_fir_ctx *ctx, uint32_t b)
@@ -235,7 +249,8 @@ static uint8_t init_common(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t u
     INIT_TRY(hipMemcpy(ctx->d_taps, pfTaps, sizeof(float) * tap_floats, hipMemcpyHostToDevice));
     INIT_TRY(hipMalloc(&ctx->d_queue, 16));
     INIT_TRY(hipMemset(ctx->d_queue, 0, 16));
-    const size_t hist_bytes = 8 * (size_t)(ulTaps > 1 ? ulTaps - 1 : 1);
+    ctx->hist_len = hist_len_for((int)ulTaps);
+    const size_t hist_bytes = 8 * (size_t)(ctx->hist_len > 0 ? ctx->hist_len : 1);
     for (int i = 0; i < 2; i++)
     {
         INIT_TRY(hipMalloc(&ctx->d_hist[i], hist_bytes));
@@ -322,7 +337,7 @@ IF_FIR_API uint8_t if_fir_reset(if_fir_ctx_t *pCtx)
     if (!pCtx)
         return 0;
     HIP_TRY(pCtx, hipSetDevice(pCtx->device));
-    const size_t hist_bytes = 8 * (size_t)(pCtx->T > 1 ? pCtx->T - 1 : 1);
+    const size_t hist_bytes = 8 * (size_t)(pCtx->hist_len > 0 ? pCtx->hist_len : 1);
     for (int i = 0; i < 2; i++)
         HIP_TRY(pCtx, hipMemsetAsync(pCtx->d_hist[i], 0, hist_bytes, pCtx->stream));
     pCtx->hist_cur = 0;
@@ -438,7 +453,10 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.in = in;
     a.out = out;
     a.taps = ctx->d_taps;
-    a.hist = ctx->d_hist[ctx->hist_cur];
+    // the kernels other than the overlap-save one look at the T-1 most recent samples: the tail of the buffer
+    a.hist_full = ctx->d_hist[ctx->hist_cur];
+    a.hist_len = ctx->hist_len;
+    a.hist = static_cast<const char *>(a.hist_full) + (size_t)(ctx->hist_len - (ctx->T - 1)) * (ctx->in_i16 ? 4 : 8);
     a.T = ctx->T;
     a.D = ctx->D;
     a.ctaps = eff_ctaps(ctx);
@@ -473,14 +491,14 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.queue_base = &ctx->queue_base;
     a.queue_valid = &ctx->queue_valid;
     // the overlap-save kernel updates the history itself (one launch per call) whenever it is launched at all
-    const bool fused_history = ctx->backend == IF_FIR_BACKEND_HIP_FFT && m > 0 && ctx->T > 1;
+    const bool fused_history = ctx->backend == IF_FIR_BACKEND_HIP_FFT && m > 0 && ctx->hist_len > 0;
     a.hist_out = fused_history ? ctx->d_hist[ctx->hist_cur ^ 1] : nullptr;
     if (ctx->backend == IF_FIR_BACKEND_HIP_FFT)
         HIP_TRY(ctx, if_fir::launch_fft(a));
     else
         HIP_TRY(ctx, if_fir::launch_fir(a, ctx->variant));
     if (!fused_history)
-        HIP_TRY(ctx, if_fir::launch_history(in, ctx->d_hist[ctx->hist_cur], ctx->d_hist[ctx->hist_cur ^ 1], ctx->T,
+        HIP_TRY(ctx, if_fir::launch_history(in, ctx->d_hist[ctx->hist_cur], ctx->d_hist[ctx->hist_cur ^ 1], ctx->hist_len,
                                             (int64_t)n, ctx->in_i16, ctx->stream));
     if (commit)
     {

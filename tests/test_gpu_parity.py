@@ -480,12 +480,16 @@ def test_multi_channel_front_one_rank(fir, oracle, torch_cuda):
 
 def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
     """The multi-channel front moves and filters a call in chunks (multiples of 215040 samples = lcm of the overlap-save
-    block advances, so blocks start where they would in one piece).  One rank, three channels, two calls with a carried
-    phase: any chunking gives bit-identical outputs, for every overlap length and for decimations 1, 4 and 3."""
+    block advances) and the contexts keep a whole block overlap of history, so the blocks of a chunked call start where
+    those of the unsplit call start and see the same samples: with the decimation phase at 0 (call lengths that are
+    multiples of the decimation) ANY chunking is bit-identical to no chunking.  With a phase p != 0 the last block of
+    a chunk would need p samples of the next chunk, which a streaming filter does not have: zeros stand in, the outputs
+    agree to rounding (checked against the bound, not bit for bit).  One rank, three channels, two calls."""
     torch = torch_cuda
-    n = 1_000_003
-    cuts = [0, 600_002, n]
-    for t, d in ((255, 4), (1023, 1), (511, 3), (2047, 4)):
+    n = 1_000_008
+    for t, d, first in ((255, 4, 600_000), (1023, 1, 600_001), (511, 3, 600_000), (2047, 4, 600_000), (255, 4, 600_002)):
+        cuts = [0, first, n]
+        exact = first % d == 0
         taps = np.stack([fir.bpf_design(t, 0.15, 0.25), fir.bpf_design(t, 0.02, 0.08), fir.bpf_design(t, 0.3, 0.45)])
         dev_in = [torch.from_numpy(oracle.synth_iq(n, 40 + c)).cuda() for c in range(3)]
         results = {}
@@ -508,11 +512,16 @@ def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
                         parts[c].append(o[:2 * m_exp])
                 results[chunk] = [np.concatenate(p) for p in parts]
         ref = results[fir.MC_NEVER_SPLIT]
+        scale = max(float(np.abs(r).max()) for r in ref)
         for chunk, res in results.items():
             for c in range(3):
-                assert np.array_equal(res[c], ref[c]), (t, d, chunk, c)
-        l2, mx = oracle.err_metrics(ref[1], oracle.fir_f64(taps[1], dev_in[1].cpu().numpy(), d))
-        assert l2 <= TOL and mx <= TOL, (t, d, l2, mx)
+                if exact:
+                    assert np.array_equal(res[c], ref[c]), (t, d, chunk, c)
+                else:
+                    assert float(np.abs(res[c] - ref[c]).max()) <= 2e-6 * scale, (t, d, chunk, c)
+        for res in results.values():
+            l2, mx = oracle.err_metrics(res[1], oracle.fir_f64(taps[1], dev_in[1].cpu().numpy(), d))
+            assert l2 <= TOL and mx <= TOL, (t, d, l2, mx)
 
 
 def test_multi_channel_bootstrap_id(fir, gpu_ok):
