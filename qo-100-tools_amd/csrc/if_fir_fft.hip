@@ -258,13 +258,14 @@ __device__ __forceinline__ cf cvt_i16(unsigned w)
     return (cf){(float)(short)(w & 0xffffu), (float)((int)w >> 16)};
 }
 // Row `row` of a block (sample row*64 + lane) whose descriptor starts at the block's first sample.  float32 rows land
-// in r[row]; int16 rows stay RAW (one dword) in rw[row] and are converted when pass 1 consumes them — converting at
+// in r[row]; int16 rows stay RAW (one dword, kept in the register of r[row].x: the row's register pair is dead until
+// pass 1 writes it, so the raw block costs no registers of its own) and are converted when pass 1 consumes them — converting at
 // the load would put a vmcnt wait right behind every prefetch.
 template <bool I16, int AUX>
-__device__ __forceinline__ void load_row(cf (&r)[64], unsigned (&rw)[64], srd_t rsrc, int lane, int row)
+__device__ __forceinline__ void load_row(cf (&r)[64], srd_t rsrc, int lane, int row)
 {
     if constexpr (I16)
-        rw[row] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)lane * 4u, row * 256, AUX);
+        r[row].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)lane * 4u, row * 256, AUX));
     else
         r[row] = buf_load<AUX>(rsrc, (unsigned)lane * 8u, row * 512);
 }
@@ -481,7 +482,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         blk = (wid < act_waves) ? (int64_t)blockIdx.x * act_waves + wid : nblocks;
     }
     cf r[64];
-    unsigned rw[64]; // raw int16 pairs of the block being loaded (I16 input only)
     bool loaded = false; // the rows of `blk` are already in flight (issued by the previous iteration's epilogue)
     const unsigned voff = (unsigned)lane * 8u;
     while (blk < nblocks)
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int rho = 0; rho < 4; rho++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX>(r, rw, srd, lane, 4 * j + rho);
+                        load_row<I16, LAUX>(r, srd, lane, 4 * j + rho);
             }
             else
             {
@@ -515,8 +515,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     const unsigned oi = (gidx >= 0) ? (unsigned)gidx * (unsigned)ISZ : 0x80000000u;
                     const unsigned oh = (gidx < 0 && hidx >= 0) ? (unsigned)hidx * (unsigned)ISZ : 0x80000000u;
                     if constexpr (I16)
-                        rw[row] = __builtin_amdgcn_raw_buffer_load_b32(srd_in, oi, 0, 0) |
-                                  __builtin_amdgcn_raw_buffer_load_b32(srd_h, oh, 0, 0);
+                        r[row].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd_in, oi, 0, 0) |
+                                                   __builtin_amdgcn_raw_buffer_load_b32(srd_h, oh, 0, 0));
                     else
                         r[row] = buf_load(srd_in, oi, 0) + buf_load(srd_h, oh, 0);
                 }
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             cf t[16];
 #pragma unroll
             for (int j = 0; j < 16; j++)
-                t[j] = I16 ? cvt_i16(rw[4 * j + rho]) : r[4 * j + rho];
+                t[j] = I16 ? cvt_i16(__float_as_uint(r[4 * j + rho].x)) : r[4 * j + rho];
             fft16<false>(t);
 #pragma unroll
             for (int j = 0; j < 16; j++)
@@ -582,10 +582,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             blk_next = queue_take(smem, gqueue, lane);
         }
         const int64_t s0n = blk_next * L - OVL + n0;
-        // (filter bank on int16 input: the raw next block would need 64 more registers next to the 64 held across the
-        //  channel loop; there the block is loaded at the top of the iteration instead -- per block the bank computes
-        //  for tens of microseconds, the exposed load is a few)
-        const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1) && !(CHAN && I16);
+        const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
         // diag 16: every wave fetches the same (cached) block -> separates HBM effects from the instruction stream's
         const int64_t s0f = (diag & 16) ? (int64_t)(lane & 0) : s0n;
         const srd_t nsrd = make_srd(in + (next_fast ? s0f : 0) * ISZ, next_fast ? (N - s0f) * ISZ : 0);
@@ -636,7 +633,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     {
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX>(r, rw, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX>(r, nsrd, lane, phys(i, j));
                     }
                 }
                 cf c[16];
@@ -647,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX>(r, rw, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX>(r, nsrd, lane, phys(i, j));
                 }
                 // mix-down of the decimated output: exp(-j 2 pi slot a / 16), a = abs0 + n0 + 4 m, m = obase + 64 r + lane
                 // with obase a multiple of 4: a call constant (rot0, host) times a quarter turn per lane
@@ -696,7 +693,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX>(r, rw, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX>(r, nsrd, lane, phys(i, j));
                 }
                 }
             FFT_STAMP(5);
@@ -709,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX>(r, rw, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX>(r, nsrd, lane, phys(i, j));
             }
             constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
             if constexpr (NCO)
@@ -830,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX>(r, rw, nsrd, lane, 4 * j + rho);
+                        load_row<I16, LAUX>(r, nsrd, lane, 4 * j + rho);
                 }
                 }
         }

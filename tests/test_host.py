@@ -216,6 +216,26 @@ def test_overlap_save_block_queue_hands_out_every_block_once(fir):
             assert counter <= s["tickets"], (nblocks, wgs_max, counter, s)
 
 
+def test_no_overlap_save_instantiation_spills():
+    """The build records the compiler's per-kernel resource remarks (csrc/if_fir_fft.resources.txt).  No instantiation of
+    the overlap-save kernel may use scratch: a spill reload behind row loads in flight waits for all of them (vmcnt is
+    in order), which defeats the prefetch the kernel is built on.  Two waves per SIMD need <= 256 VGPRs."""
+    path = os.path.join(ROOT, "qo-100-tools_amd", "csrc", "if_fir_fft.resources.txt")
+    assert os.path.exists(path), "build() first: the Makefile writes this file next to if_fir_fft.o"
+    kernels, cur = {}, None
+    for line in open(path):
+        k, _, v = line.strip().partition(":")
+        if k == "Function Name":
+            cur = v.strip()
+            kernels[cur] = {}
+        elif cur:
+            kernels[cur][k.split("[")[0].strip()] = int(v)
+    fft = {k: v for k, v in kernels.items() if "fir_fft_kernel" in k}
+    assert len(fft) == 70, len(fft)          # 5 overlap lengths x (4 + 4 + 4 single-channel, 2 filter-bank) variants
+    for name, res in fft.items():
+        assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
+
+
 def test_bench_line_contract_on_the_committed_run():
     """The bench.py JSON line of the last profiled run (profiles/*_bench.json, produced on the GPU box) carries every
     field the driver's contract names, with the right types, and its numbers are mutually consistent."""
