@@ -46,7 +46,7 @@ enum
     IF_FIR_BACKEND_HIP_DIRECT = 1,  /* register-blocked sample-stationary direct form, taps in SGPRs            */
     IF_FIR_BACKEND_HIP_TAPSPLIT = 2,/* any T, D: taps staged in LDS, split over 4 lanes, partial sums DPP-reduced */
     IF_FIR_BACKEND_HIP_GENERIC = 3, /* any T, D: one output per thread (simple cross-check kernel)                */
-    IF_FIR_BACKEND_HIP_FFT = 4      /* overlap-save, wave-private 4096-point FFT (T ≤ 3073, any D ≤ 64); AUTO's pick */
+    IF_FIR_BACKEND_HIP_FFT = 4      /* overlap-save, wave-private 4096-point FFT (any T ≤ 4096, any D ≤ 64); AUTO's pick */
 };
 
 /* input sample formats (if_fir_set_input_format) */

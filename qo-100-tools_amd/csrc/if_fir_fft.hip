@@ -369,15 +369,18 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
     fft16<true>(c); // over k0 -> mu0
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN, bool DECN>
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN, bool DECN, bool ACC>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int HL, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
                                                         unsigned int *queue, unsigned long long *dbg, int32_t diag,
                                                         uint32_t nco_phi0, uint32_t nco_delta, ChanArgs chan,
                                                         uint32_t qsel, void *__restrict__ hist_out,
-                                                        int32_t decn, int32_t decn_n0, int64_t decn_m)
+                                                        int32_t decn, int32_t decn_n0, int64_t decn_m, int32_t in_shift)
 {
+    // ACC (filters of 3074..4096 taps, two partitions of <= 2048 taps): this launch filters the input DELAYED by in_shift
+    // samples with the second partition's table and adds its result to what the first launch stored
+    static_assert(!ACC || (!DEC4 && !CHAN && OVL_ROWS == 32), "accumulating store: full-rate pipeline, 32 overlap rows");
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
     static_assert(!CHAN || (DEC4 && !NCO), "the channelizer is a decimate-by-4 variant");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     while (blk < nblocks)
     {
         FFT_STAMP(0);
-        const int64_t s0 = blk * L - OVL + n0; // stream index of the block's first sample (n0: decimation phase)
+        const int64_t s0 = blk * L - OVL + n0 - in_shift; // stream index of the block's first sample (n0: decimation phase)
         if (!loaded && !(diag & 1))
         {
             if (s0 >= 0)
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             // behind the (rare) global atomic inside drains nothing
             blk_next = queue_take(smem, gqueue, lane);
         }
-        const int64_t s0n = blk_next * L - OVL + n0;
+        const int64_t s0n = blk_next * L - OVL + n0 - in_shift;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
         // diag 16: every wave fetches the same (cached) block -> separates HBM effects from the instruction stream's
         const int64_t s0f = (diag & 16) ? (int64_t)(lane & 0) : s0n;
@@ -817,10 +820,17 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                             const unsigned qd = (u * dmagic) >> 18;
                             const int rel = drel0 + (int)qd;
                             const bool keep = (u - qd * (unsigned)decn == 0u) && rel >= 0;
-                            buf_store(dsrd, keep ? (unsigned)rel * 8u : 0xffffffffu, 0, t[j]); // out of range = dropped
+                            const unsigned so = keep ? (unsigned)rel * 8u : 0xffffffffu; // out of range = dropped
+                            if constexpr (ACC)
+                                t[j] += buf_load(dsrd, so, 0);
+                            buf_store(dsrd, so, 0, t[j]);
                         }
                         else
+                        {
+                            if constexpr (ACC)
+                                t[j] += buf_load(osrd, voff, (row - OVL_ROWS) * 512);
                             buf_store(osrd, voff, (row - OVL_ROWS) * 512, t[j]);
+                        }
                     }
                 }
                 if (next_fast)
@@ -865,10 +875,10 @@ void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s)
     s.tickets = groups + 2 * s.wgs; // upper bound of the counter at the end of the launch
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN = false, bool DECN = false>
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN = false, bool DECN = false, bool ACC = false>
 static hipError_t launch_fft_t(const LaunchArgs &a)
 {
-    auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN>;
+    auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN, ACC>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
     constexpr int LOUT = DEC4 ? L / 4 : L;
     static DeviceSetup setup;
@@ -911,7 +921,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
                        n0_rate, m_rate, nblocks, (unsigned int *)a.queue,
                        (unsigned long long *)a.dbg, (int32_t)a.diag,
                        DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a), DECN ? 0u - a.nco_word : nco_delta(a),
-                       a.chan ? *a.chan : ChanArgs{}, qsel, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M);
+                       a.chan ? *a.chan : ChanArgs{}, qsel, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M,
+                       (int32_t)a.in_shift);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess && a.queue_valid)
         *a.queue_valid = false; // nothing ran: the counters are in an unknown state
@@ -923,11 +934,20 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 // 64): up to 257 taps cost 6 % of the block, 513 taps 12.5 %, 1025 taps 25 %, 2049 taps half, 3073 taps three quarters.
 bool fft_supported(int T, int D)
 {
-    return D >= 1 && D <= 64 && T >= 1 && T <= 3073;
+    return D >= 1 && D <= 64 && T >= 1 && T <= 4096;
+}
+
+// 3074..4096 taps: two partitions of at most FFT_PART taps each, y = h_a * x + h_b * (x delayed by FFT_PART)
+constexpr int FFT_PART = 2048;
+bool fft_two_partitions(int T)
+{
+    return T > 3073;
 }
 
 int fft_overlap_rows(int T)
 {
+    if (fft_two_partitions(T))
+        return 32; // each partition runs the 32-row kernel
     return (T - 1 <= 256) ? 4 : (T - 1 <= 512) ? 8 : (T - 1 <= 1024) ? 16 : (T - 1 <= 2048) ? 32 : 48;
 }
 
@@ -966,10 +986,66 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
     }
 }
 
+// second partition: input delayed by FFT_PART samples, table B, accumulate into the outputs of the first launch
+static hipError_t launch_fft_acc(const LaunchArgs &a)
+{
+    const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
+    if (a.D == 1)
+        switch (key)
+        {
+        case 0: return launch_fft_t<32, false, false, false, false, false, true>(a);
+        case 1: return launch_fft_t<32, false, false, true, false, false, true>(a);
+        case 2: return launch_fft_t<32, false, true, false, false, false, true>(a);
+        default: return launch_fft_t<32, false, true, true, false, false, true>(a);
+        }
+    switch (key)
+    {
+    case 0: return launch_fft_t<32, false, false, false, false, true, true>(a);
+    case 1: return launch_fft_t<32, false, false, true, false, true, true>(a);
+    case 2: return launch_fft_t<32, false, true, false, false, true, true>(a);
+    default: return launch_fft_t<32, false, true, true, false, true, true>(a);
+    }
+}
+
 hipError_t launch_fft(const LaunchArgs &a)
 {
     if (!fft_supported(a.T, a.D) || !a.fft_tables)
         return hipErrorInvalidConfiguration;
+    if (fft_two_partitions(a.T))
+    {
+        // Filters of 3074..4096 taps: h = (h_a, h_b) with 2048 taps in h_a.  Launch 1: y = h_a * x (writes the history);
+        // launch 2: y += h_b * x(n - 2048).  Both are the 32-row (2049-tap) kernel at full rate; a decimation other than 1
+        // (4 included) goes through the selecting store.  The history holds 4096 samples: 2048 of delay + the overlap.
+        if (a.chan || !a.fft_tables_b || a.hist_len < 2 * FFT_PART)
+            return hipErrorInvalidConfiguration;
+        LaunchArgs p = a;
+        p.T = FFT_PART;
+        const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
+        hipError_t e;
+        if (a.D == 1)
+            switch (key)
+            {
+            case 0: e = launch_fft_t<32, false, false, false>(p); break;
+            case 1: e = launch_fft_t<32, false, false, true>(p); break;
+            case 2: e = launch_fft_t<32, false, true, false>(p); break;
+            default: e = launch_fft_t<32, false, true, true>(p); break;
+            }
+        else
+            switch (key)
+            {
+            case 0: e = launch_fft_t<32, false, false, false, false, true>(p); break;
+            case 1: e = launch_fft_t<32, false, false, true, false, true>(p); break;
+            case 2: e = launch_fft_t<32, false, true, false, false, true>(p); break;
+            default: e = launch_fft_t<32, false, true, true, false, true>(p); break;
+            }
+        if (e != hipSuccess)
+            return e;
+        p.T = a.T - FFT_PART;
+        p.fft_tables = a.fft_tables_b;
+        p.in_shift = FFT_PART;
+        p.hist_out = nullptr; // the first launch wrote the next history
+        return launch_fft_acc(p);
+    }
     switch (fft_overlap_rows(a.T))
     {
     case 4: return launch_fft_rows<4>(a);

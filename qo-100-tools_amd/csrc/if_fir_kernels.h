@@ -46,6 +46,8 @@ struct LaunchArgs
     int device;
     hipStream_t stream;
     const void *fft_tables; // device, FFT_TABLE_FLOATS floats (overlap-save backend) or nullptr
+    const void *fft_tables_b; // second partition's tables (3074..4096 taps) or nullptr
+    int in_shift;             // overlap-save kernel: the input is read delayed by this many samples (second partition)
     void *queue; // device, 16 bytes: atomic run queue of the persistent kernel (zeroed by the launcher)
     int diag;  // development diagnostics for the FFT kernel (0 in production)
     int grid_limit; // FFT backend: at most this many workgroups (0 = one per CU); same results, used by the queue tests
@@ -112,6 +114,7 @@ hipError_t launch_fir(const LaunchArgs &a, int variant);
 // overlap-save FFT backend (if_fir_fft.hip)
 constexpr int FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024 + 64); // ... + 64 NCO row phasors
 bool fft_supported(int T, int D);
+bool fft_two_partitions(int T); // 3074..4096 taps: two launches (2048 + the rest), see launch_fft
 struct FftSchedule
 {
     int64_t RA, nA, RB, nB, tickets, wgs; // blocks per group, groups, static groups per workgroup, 0, ticket bound, workgroups

@@ -79,11 +79,11 @@ static void set_err(const if_fir_ctx *ctx, const char *fmt, ...)
 static inline int eff_ctaps(const if_fir_ctx *ctx) { return ctx->ctaps || ctx->nco_word; }
 static inline const float *eff_taps(const if_fir_ctx *ctx) { return ctx->h_eff ? ctx->h_eff : ctx->h_taps; }
 
-// AUTO: the fastest backend that meets SPEC §3.  Measured over (taps, decimation) from 3 taps to 3073 and decimation
-// 1 to 64 (tools/policy_sweep.py, profiles/r01d_policy_sweep.txt) the overlap-save kernel wins wherever it applies --
-// its cost is that of streaming the data, whatever the tap count -- so it is the pick for every T <= 3073; longer
-// filters go to the tap-split kernel.  The unrolled direct form (bit-reproducible order) and the generic kernel
-// (cross-check) are there on request.
+// AUTO: the fastest backend that meets SPEC §3.  Measured over (taps, decimation) from 3 taps to 4095 and decimation
+// 1 to 64 (tools/policy_sweep.py, profiles/r01d_policy_sweep.txt, r02_policy_sweep.txt) the overlap-save kernel wins
+// wherever it applies -- its cost is that of streaming the data, whatever the tap count -- so it is the pick for every
+// filter the library accepts (3074..4096 taps as two partitions).  The unrolled direct form (bit-reproducible order),
+// the tap-split kernel (the north_star's wording) and the generic kernel (cross-check) are there on request.
 static uint32_t resolve_backend(const if_fir_ctx *ctx, uint32_t req)
 {
     if (req != IF_FIR_BACKEND_AUTO)
@@ -104,6 +104,8 @@ static int hist_len_for(int T)
     const int need = T > 1 ? T - 1 : 0;
     if (!if_fir::fft_supported(T, 1))
         return need;
+    if (if_fir::fft_two_partitions(T))
+        return 4096; // second partition: 2048 samples of delay + the 2048-sample block overlap
     const int ovl = 64 * if_fir::fft_overlap_rows(T);
     return ovl > need ? ovl : need;
 }
@@ -131,7 +133,10 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
 {
     if (ctx->d_fft_tables)
         return 1;
-    float *tab = (float *)malloc(sizeof(float) * if_fir::FFT_TABLE_FLOATS);
+    // 3074..4096 taps run as two partitions (2048 taps + the rest): two table images back to back
+    const bool two = if_fir::fft_two_partitions(ctx->T);
+    const size_t tab_floats = (size_t)if_fir::FFT_TABLE_FLOATS * (two ? 2 : 1);
+    float *tab = (float *)malloc(sizeof(float) * tab_floats);
     if (!tab)
     {
         set_err(ctx, "overlap-save tables: out of host memory");
@@ -139,13 +144,22 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
     }
     // NCO row phasors: per kept output for the decimate-by-4 kernel, per full-rate output for all others
     // int16 input: the kernel leaves the samples unscaled and the table carries the format's 2^-15
-    if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (ctx->D == 4 ? 4u : 1u),
-                             ctx->in_i16 ? 0x1p-15 : 1.0, tab);
+    if (two)
+    {
+        // full-rate tables (the decimation, 4 included, is a selecting store on this path)
+        const int step = eff_ctaps(ctx) ? 2 : 1, part = 2048;
+        if_fir::fft_build_tables(eff_taps(ctx), part, eff_ctaps(ctx), 1, 0u - ctx->nco_word, ctx->in_i16 ? 0x1p-15 : 1.0, tab);
+        if_fir::fft_build_tables(eff_taps(ctx) + (size_t)step * part, ctx->T - part, eff_ctaps(ctx), 1, 0u - ctx->nco_word,
+                                 ctx->in_i16 ? 0x1p-15 : 1.0, tab + if_fir::FFT_TABLE_FLOATS);
+    }
+    else
+        if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (ctx->D == 4 ? 4u : 1u),
+                                 ctx->in_i16 ? 0x1p-15 : 1.0, tab);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
-        e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
+        e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * tab_floats);
     if (e == hipSuccess)
-        e = hipMemcpy(ctx->d_fft_tables, tab, sizeof(float) * if_fir::FFT_TABLE_FLOATS, hipMemcpyHostToDevice);
+        e = hipMemcpy(ctx->d_fft_tables, tab, sizeof(float) * tab_floats, hipMemcpyHostToDevice);
     free(tab);
     if (e != hipSuccess)
     {
@@ -470,6 +484,8 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.device = ctx->device;
     a.stream = ctx->stream;
     a.fft_tables = ctx->d_fft_tables;
+    a.fft_tables_b = (ctx->d_fft_tables && if_fir::fft_two_partitions(ctx->T))
+                         ? static_cast<const float *>(ctx->d_fft_tables) + if_fir::FFT_TABLE_FLOATS : nullptr;
     a.queue = ctx->d_queue;
     a.dbg = ctx->d_dbg;
     // FFT tuning variants: 1000 + bits = development diagnostics (wrong results), 2000 + k = launch at most k workgroups
@@ -540,7 +556,8 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
         set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot and output arrays", if_fir::CHAN_MAX);
         return 0;
     }
-    if (pCtx->D != 4 || pCtx->ctaps || pCtx->nco_word || !if_fir::fft_supported(pCtx->T, pCtx->D))
+    if (pCtx->D != 4 || pCtx->ctaps || pCtx->nco_word || !if_fir::fft_supported(pCtx->T, pCtx->D) ||
+        if_fir::fft_two_partitions(pCtx->T))
     {
         set_err(pCtx, "if_fir_channelizer_process_device: needs real taps (<= 3073), decimation 4, no NCO");
         return 0;

@@ -34,13 +34,14 @@ def test_library_loaded_is_in_tree(fir, gpu_ok):
 
 
 def test_auto_backend_policy(fir, gpu_ok):
-    """AUTO = overlap-save wherever it applies (<= 3073 taps, any decimation: it is the fastest there in every case
-    measured, tools/policy_sweep.py), else tap-split."""
+    """AUTO = overlap-save for every filter the library accepts (any decimation: it is the fastest in every case
+    measured, tools/policy_sweep.py); 3074..4096 taps run as two partitions."""
     expect = {(255, 4): fir.BACKEND_HIP_FFT, (255, 1): fir.BACKEND_HIP_FFT, (127, 1): fir.BACKEND_HIP_FFT,
               (1023, 1): fir.BACKEND_HIP_FFT, (1023, 4): fir.BACKEND_HIP_FFT, (31, 1): fir.BACKEND_HIP_FFT,
               (3, 1): fir.BACKEND_HIP_FFT, (255, 2): fir.BACKEND_HIP_FFT, (1023, 8): fir.BACKEND_HIP_FFT,
               (255, 16): fir.BACKEND_HIP_FFT, (63, 64): fir.BACKEND_HIP_FFT, (2047, 1): fir.BACKEND_HIP_FFT,
-              (3073, 4): fir.BACKEND_HIP_FFT, (3075, 1): fir.BACKEND_HIP_TAPSPLIT, (4095, 4): fir.BACKEND_HIP_TAPSPLIT}
+              (3073, 4): fir.BACKEND_HIP_FFT, (3075, 1): fir.BACKEND_HIP_FFT, (4095, 4): fir.BACKEND_HIP_FFT,
+              (4095, 64): fir.BACKEND_HIP_FFT}
     for (t, d), b in expect.items():
         with fir.IfFir(fir.bpf_design(t), d, 16) as f:
             assert f.get_backend() == b, (t, d)
@@ -298,9 +299,11 @@ def test_fft_backend_run_queue_on_small_grid(fir, oracle, t, d, i16):
 def test_fft_backend_rejects_unsupported(fir):
     with fir.IfFir(fir.bpf_design(255), 3, 1000) as f:
         f.set_backend(fir.BACKEND_HIP_FFT)            # any decimation (full-rate kernel + selecting store)
-    with fir.IfFir(fir.bpf_design(3075), 1, 1000) as f:
-        with pytest.raises(fir.IfFirError):
-            f.set_backend(fir.BACKEND_HIP_FFT)        # more than 3073 taps: less than a quarter of a block would be new
+    with fir.IfFir(fir.bpf_design(3075), 4, 1000) as f:
+        f.set_backend(fir.BACKEND_HIP_FFT)            # more than 3073 taps: two partitions of up to 2048 taps
+        out = [0] * 2
+        with pytest.raises(fir.IfFirError, match="filter bank|needs real taps"):
+            f.channelizer_process_device([1, 3], 0, out, 16)   # the filter bank is a single-partition kernel
 
 
 @pytest.mark.parametrize("t", [255, 127, 1023, 257, 259, 513])
@@ -688,8 +691,7 @@ def test_random_configurations_against_the_oracle(fir, oracle):
             choices.append(fir.BACKEND_HIP_TAPSPLIT)
             if t in (127, 255) and d in (1, 4):
                 choices.append(fir.BACKEND_HIP_DIRECT)
-        if t <= 3073:
-            choices += [fir.BACKEND_HIP_FFT] * 2
+        choices += [fir.BACKEND_HIP_FFT] * 2
         b = fir.BACKEND_HIP_DIRECT if case % 6 == 0 else int(rng.choice(choices))
         cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))]))
         ref = oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(nco)) if nco else oracle.fir_f64(taps, x, d)
@@ -838,6 +840,60 @@ def test_fft_backend_long_filters(fir, oracle, t, d):
     with fir.IfFir(g, d, n, complex_taps=True) as f:
         l2, mx = oracle.err_metrics(f.process(x), oracle.fir_ctaps_f64(g, x, d))
         assert l2 <= TOL and mx <= TOL, ("ctaps", l2, mx)
+
+
+@pytest.mark.parametrize("t,d", [(3075, 1), (3075, 4), (3075, 8), (4095, 1), (4095, 4), (4095, 8), (4096, 1), (4096, 4),
+                                 (4096, 8), (3074, 3)])
+def test_fft_backend_two_partitions(fir, oracle, t, d):
+    """3074..4096 taps on the overlap-save backend: h = (h_a, h_b) with 2048 taps in h_a; one launch
+    computes h_a * x, a second one adds h_b * x(n - 2048) (the same 32-row kernel reading the input 2048 samples late,
+    accumulating store).  Against the float64 oracle: one call, ragged pieces shorter and longer than the delay, a
+    small grid, int16 input, complex taps, the NCO; and against the tap-split kernel."""
+    rng = np.random.default_rng(t + d)
+    def design(lo, hi):                                  # the designer makes odd lengths: an even one gets a small last tap
+        if t % 2:
+            return fir.bpf_design(t, lo, hi)
+        return np.concatenate([fir.bpf_design(t - 1, lo, hi), np.array([0.001], np.float32)]).astype(np.float32)
+
+    taps = design(0.15, 0.25)
+    n = 90_001
+    x = np.concatenate([oracle.synth_iq(n // 2, 33), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
+    ref = oracle.fir_f64(taps, x, d)
+    with fir.IfFir(taps, d, n) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        for tuning in (0, 2001):
+            f.set_tuning(tuning)
+            f.reset()
+            y = f.process(x)
+            l2, mx = oracle.err_metrics(y, ref)
+            assert l2 <= TOL and mx <= TOL, (tuning, l2, mx)
+        f.set_tuning(0)
+        f.reset()
+        cuts = [0, 3, 1000, 2047, 2048, 2049, 4100, 6200, 30_001, 30_002, 70_000, n]
+        parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
+        assert l2 <= TOL and mx <= TOL, ("pieces", l2, mx)
+        f.set_backend(fir.BACKEND_HIP_TAPSPLIT)
+        f.reset()
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(f.process(x) - y).max()) <= 2e-6 * scale
+    if d in (1, 4):
+        xi = np.clip(np.round(x * 8000.0), -32768, 32767).astype(np.int16)
+        with fir.IfFir(taps, d, n) as f:
+            f.set_input_format(fir.INPUT_I16)
+            parts = [f.process(xi[:2 * 40_001]), f.process(xi[2 * 40_001:])]
+            l2, mx = oracle.err_metrics(np.concatenate(parts), oracle.fir_f64(taps, xi.astype(np.float32) * np.float32(2.0 ** -15), d))
+            assert l2 <= TOL and mx <= TOL, ("i16", l2, mx)
+        g = (rng.standard_normal(2 * t) / np.sqrt(t)).astype(np.float32)
+        with fir.IfFir(g, d, n, complex_taps=True) as f:
+            l2, mx = oracle.err_metrics(f.process(x), oracle.fir_ctaps_f64(g, x, d))
+            assert l2 <= TOL and mx <= TOL, ("ctaps", l2, mx)
+        lp = design(0.0, 0.05)
+        with fir.IfFir(lp, d, n) as f:
+            f.set_nco(0.2003)
+            parts = [f.process(x[:2 * 50_003]), f.process(x[2 * 50_003:])]
+            l2, mx = oracle.err_metrics(np.concatenate(parts), oracle.fir_nco_f64(lp, x, d, oracle.nco_phase_word(0.2003)))
+            assert l2 <= TOL and mx <= TOL, ("nco", l2, mx)
 
 
 @pytest.mark.parametrize("d,i16", [(4, False), (3, False), (4, True), (1, False)])

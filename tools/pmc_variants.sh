@@ -10,7 +10,8 @@ shift
 cd /tmp
 for v in "$@"; do
   rm -rf $R/gpurun_out/pmcv_$v
-  rocprofv3 --pmc "${CTRS[@]}" --output-format csv -d $R/gpurun_out/pmcv_$v -- python3 $R/tools/sweep.py $WL $v > $R/gpurun_out/pmcv_$v.log 2>&1 || exit 1
+  # a counter set the profiler rejects can leave it hanging after its abort: bound every pass
+  timeout -k 5 ${PMC_TIMEOUT:-120} rocprofv3 --pmc "${CTRS[@]}" --output-format csv -d $R/gpurun_out/pmcv_$v -- python3 $R/tools/sweep.py $WL $v > $R/gpurun_out/pmcv_$v.log 2>&1 || { echo "== variant $v: pass failed or timed out (${CTRS[*]})"; exit 1; }
   echo "== variant $v: $(grep variant $R/gpurun_out/pmcv_$v.log | cut -c1-60)"
-  python3 $R/tools/pmc_summary.py $R/gpurun_out/pmcv_$v | grep -A20 fir_fft
+  python3 $R/tools/pmc_summary.py $R/gpurun_out/pmcv_$v | grep -A20 -E 'fir_fft|fir_direct'
 done
