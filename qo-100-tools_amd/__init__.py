@@ -10,3 +10,4 @@ The directory name is not a Python identifier; load it with `__graft_entry__.loa
 from . import if_fir  # noqa: F401
 from . import channel_shard  # noqa: F401
 from . import wb_detect  # noqa: F401
+from . import rc_reg  # noqa: F401

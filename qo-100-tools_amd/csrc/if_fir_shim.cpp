@@ -110,6 +110,12 @@ static int hist_len_for(int T)
     return ovl > need ? ovl : need;
 }
 
+static bool debug_enabled()
+{
+    const char *e = getenv("IF_FIR_DEBUG");
+    return e && *e && *e != '0';
+}
+
 static bool backend_ok(const if_fir_ctx *ctx, uint32_t b)
 {
     if ((eff_ctaps(ctx) || ctx->in_i16) && b != IF_FIR_BACKEND_HIP_FFT && b != IF_FIR_BACKEND_HIP_GENERIC)
@@ -279,7 +285,8 @@ static uint8_t init_common(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t u
         if_fir_destroy(ctx);
         return 0;
     }
-    const char *v = getenv("IF_FIR_VARIANT");
+    // development only: IF_FIR_DEBUG=1 IF_FIR_VARIANT=n preselects a tuning variant (ignored in production)
+    const char *v = debug_enabled() ? getenv("IF_FIR_VARIANT") : nullptr;
     ctx->variant = v ? atoi(v) : 0;
     ctx->err[0] = 0;
     *ppCtx = ctx;
@@ -386,6 +393,14 @@ IF_FIR_API uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant)
 {
     if (!pCtx)
         return 0;
+    // 1000..1999 are diagnostic launches of the overlap-save kernel that skip loads or stores (WRONG results, for
+    // timing studies): refused unless the process runs with IF_FIR_DEBUG=1.  Everything else changes speed only.
+    if (ulVariant >= 1000 && ulVariant < 2000 && !debug_enabled())
+    {
+        set_err(pCtx, "if_fir_set_tuning: variant %u is a diagnostic launch (wrong results); set IF_FIR_DEBUG=1 to allow it",
+                ulVariant);
+        return 0;
+    }
     pCtx->variant = (int)ulVariant;
     return 1;
 }

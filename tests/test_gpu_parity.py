@@ -296,6 +296,25 @@ def test_fft_backend_run_queue_on_small_grid(fir, oracle, t, d, i16):
         assert l2 <= TOL and mx <= TOL, (l2, mx)
 
 
+def test_diagnostic_variants_need_the_debug_switch(fir, gpu_ok):
+    """Tuning variants 1000..1999 are timing diagnostics that skip loads or stores (wrong results): the shipped ABI
+    refuses them unless the process runs with IF_FIR_DEBUG=1; variants that only change speed stay open."""
+    old = os.environ.pop("IF_FIR_DEBUG", None)
+    try:
+        with fir.IfFir(fir.bpf_design(255), 4, 1000) as f:
+            with pytest.raises(fir.IfFirError, match="diagnostic"):
+                f.set_tuning(1001)
+            f.set_tuning(2003)
+            f.set_tuning(0)
+            os.environ["IF_FIR_DEBUG"] = "1"
+            f.set_tuning(1032)
+            f.set_tuning(0)
+    finally:
+        os.environ.pop("IF_FIR_DEBUG", None)
+        if old is not None:
+            os.environ["IF_FIR_DEBUG"] = old
+
+
 def test_fft_backend_rejects_unsupported(fir):
     with fir.IfFir(fir.bpf_design(255), 3, 1000) as f:
         f.set_backend(fir.BACKEND_HIP_FFT)            # any decimation (full-rate kernel + selecting store)

@@ -3,6 +3,7 @@
 (development tool): every wave stamps s_memrealtime (100 MHz) and s_memtime (shader clock) at its start and end; the
 clock is the quotient over the launch.  Variants as in tools/sweep.py (1000 + diagnostic bits)."""
 import os
+os.environ.setdefault("IF_FIR_DEBUG", "1")   # development tool: diagnostic tuning variants allowed
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """fft_stamps.py — phase timing of the overlap-save kernel's wave loop (development tool)."""
 import os
+os.environ.setdefault("IF_FIR_DEBUG", "1")   # development tool: diagnostic tuning variants allowed
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,7 @@
 """sweep.py — times every tuning variant of one workload through the C-ABI (development tool).
 usage: python tools/sweep.py [workload] [variants...]"""
 import os, sys
+os.environ.setdefault("IF_FIR_DEBUG", "1")   # development tool: diagnostic tuning variants allowed
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
