@@ -728,8 +728,8 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps
                                             uint32_t ulDecimation, uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats)
 {
     if (!pfTaps || !pfOut || ulOutFloats < (uint32_t)if_fir::FFT_TABLE_FLOATS ||
-        !if_fir::fft_supported((int)ulTaps, (int)ulDecimation))
-        return 0;
+        !if_fir::fft_supported((int)ulTaps, (int)ulDecimation) || if_fir::fft_two_partitions((int)ulTaps))
+        return 0; // (a two-partition filter is two such images, one per partition of <= 2048 taps)
     if_fir::fft_build_tables(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, (int)ulDecimation, ulNcoDelta, 1.0, pfOut);
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
 }
