@@ -474,10 +474,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     }
     // Work distribution: see queue_take()
     const int32_t waves_total = (int32_t)gridDim.x * FFT_WAVES;
-    int64_t blk = (diag & 32) ? 0 : queue_take(smem, gqueue, lane);
+    // diag 64 (development, results stay correct): waves 4-7 of every workgroup leave at once = one wave per SIMD
+    // (occupancy experiment; the queue hands their share to the others)
+    int64_t blk = (diag & 32) ? 0 : ((diag & 64) && wid >= FFT_WAVES / 2) ? nblocks : queue_take(smem, gqueue, lane);
     // diag 32 (development, results stay correct): static wave-interleaved blocks, no queue: block = it * waves + wave
     const bool static_map = (diag & 32) != 0;
-    // diag 64 (with 32): only waves 0-3 of each workgroup work = one wave per SIMD (occupancy experiment)
     const int act_waves = (diag & 64) ? FFT_WAVES / 2 : FFT_WAVES;
     const int64_t static_stride = (int64_t)(waves_total / FFT_WAVES) * act_waves;
     if (static_map)
