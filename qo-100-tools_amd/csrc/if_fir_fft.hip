@@ -236,10 +236,12 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 }
 // Cache policy of the streams (aux bits of the buffer instructions: 2 = nt, non-temporal).  Measured on 2^28 samples
 // (profiles/r02_nt_ab.txt): nt stores help every configuration (255 taps /4: 0.502 -> 0.482 ms, the outputs are never
-// read again); nt row loads help while the overlap is small (another 0.002-0.02 ms at 4 overlap rows) and cost 3 % at
-// 16 overlap rows, where a quarter of every block is re-read by the neighbouring wave and should stay cached.
+// read again).  Row loads: the rows a block shares with its neighbours (the first and last OVL_ROWS rows) keep the
+// default policy -- the neighbouring block is being loaded by the next wave of the same workgroup at about the same
+// time and finds them in L2: HBM reads 2.269 -> 2.161 GB per launch = 1.006 x algorithmic, -2 % time -- and the rows
+// in between, which nobody reads again, are nt.  (nt on ALL rows costs 3 % at 16 overlap rows.)
 #ifndef IF_FIR_FFT_LOAD_AUX
-#define IF_FIR_FFT_LOAD_AUX(ovl_rows) ((ovl_rows) <= 4 ? 2 : 0)
+#define IF_FIR_FFT_LOAD_AUX(ovl_rows) 2
 #endif
 #ifndef IF_FIR_FFT_STORE_AUX
 #define IF_FIR_FFT_STORE_AUX 2
@@ -262,12 +264,25 @@ __device__ __forceinline__ cf cvt_i16(unsigned w)
 // pass 1 writes it, so the raw block costs no registers of its own) and are converted when pass 1 consumes them — converting at
 // the load would put a vmcnt wait right behind every prefetch.
 template <bool I16, int AUX>
-__device__ __forceinline__ void load_row(cf (&r)[64], srd_t rsrc, int lane, int row)
+__device__ __forceinline__ void load_row_aux(cf (&r)[64], srd_t rsrc, int lane, int row)
 {
     if constexpr (I16)
         r[row].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)lane * 4u, row * 256, AUX));
     else
         r[row] = buf_load<AUX>(rsrc, (unsigned)lane * 8u, row * 512);
+}
+// EDGE rows: the first and last `EDGE` rows of a block are the rows the neighbouring block shares with it; loaded with
+// the default policy they are served to the neighbour from L2 (IF_FIR_FFT_EDGE_CACHED=0 switches that off for A/B runs)
+#ifndef IF_FIR_FFT_EDGE_CACHED
+#define IF_FIR_FFT_EDGE_CACHED 1
+#endif
+template <bool I16, int AUX, int EDGE = 0>
+__device__ __forceinline__ void load_row(cf (&r)[64], srd_t rsrc, int lane, int row)
+{
+    if (IF_FIR_FFT_EDGE_CACHED && AUX != 0 && (row < EDGE || row >= 64 - EDGE)) // `row` is a constant after unrolling
+        load_row_aux<I16, 0>(r, rsrc, lane, row);
+    else
+        load_row_aux<I16, AUX>(r, rsrc, lane, row);
 }
 __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned soff, cf d)
 {
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int rho = 0; rho < 4; rho++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX>(r, srd, lane, 4 * j + rho);
+                        load_row<I16, LAUX, OVL_ROWS>(r, srd, lane, 4 * j + rho);
             }
             else
             {
@@ -637,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     {
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
                     }
                 }
                 cf c[16];
@@ -648,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
                 }
                 // mix-down of the decimated output: exp(-j 2 pi slot a / 16), a = abs0 + n0 + 4 m, m = obase + 64 r + lane
                 // with obase a multiple of 4: a call constant (rot0, host) times a quarter turn per lane
@@ -697,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
                 }
                 }
             FFT_STAMP(5);
@@ -710,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
             }
             constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
             if constexpr (NCO)
@@ -838,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX>(r, nsrd, lane, 4 * j + rho);
+                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, 4 * j + rho);
                 }
                 }
         }
