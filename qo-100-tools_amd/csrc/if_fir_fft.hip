@@ -404,7 +404,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     const char *in = reinterpret_cast<const char *>(in_);
     constexpr int L = FFT_N - OVL;         // new input samples per block
     constexpr int LOUT = DEC4 ? L / 4 : L; // outputs per block
-    constexpr int EARLY_GROUPS = 3;        // dec4: batches of next-block loads issued during pass 3
+#ifndef IF_FIR_FFT_EARLY_GROUPS
+#define IF_FIR_FFT_EARLY_GROUPS 3
+#endif
+    constexpr int EARLY_GROUPS = IF_FIR_FFT_EARLY_GROUPS; // dec4: batches of next-block loads issued during pass 3
     constexpr int LAUX = IF_FIR_FFT_LOAD_AUX(OVL_ROWS); // cache policy of the row loads
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
