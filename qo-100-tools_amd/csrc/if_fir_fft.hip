@@ -297,14 +297,18 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
 // at any moment the chip works on one compact window of the stream (DRAM pages and the overlap rows of neighbouring
 // blocks are shared by waves that run at the same time), and no wave holds work another one could do.
 //   * level 1, LDS: a wave takes the next SLOT of its workgroup (ds_add_rtn): slot s = block s % 8 of local group s / 8;
-//   * level 2, global: the wave that takes slot 0 of local group g fetches the global group of local group g + 2 with
-//     one returning atomic (waited for on the spot: it sits where nothing else of this wave is in flight) and
-//     publishes it in an LDS ring; local groups 0 and 1 are static (workgroup b: global groups b and wgs + b).
+//   * level 2, global: the wave that takes slot 0 of local group g fetches the global group of local group g + Q_AHEAD
+//     with one returning atomic (waited for on the spot: it sits where nothing else of this wave is in flight) and
+//     publishes it in an LDS ring; the first Q_AHEAD local groups are static (workgroup b: global groups b, wgs + b).
 // One global atomic per 8 blocks (a single address takes ~88 atomics/us; 70 k blocks in 0.5 ms would be 140/us), two
-// groups of slack before anybody needs its result.  A ring entry is {local group, global group} in one 8-byte LDS word.
+// groups (16 slot takes = two block times, ~28 us) of slack before anybody needs its result.  (Q_AHEAD 1 measured the
+// same, 0.478 vs 0.474 ms interleaved: the waves of a launch finish over two block times either way, which is the
+// group granularity -- the last group a workgroup receives takes a block time to hand out and one to run --, not the
+// reserve.)  A ring entry is {local group, global group} in one 8-byte LDS word.
+constexpr unsigned Q_AHEAD = 2; // groups fetched ahead = static groups per workgroup
 __host__ __device__ __forceinline__ constexpr int64_t fft_static_group(int local_group, int64_t wg, int64_t wgs)
 {
-    return local_group == 0 ? wg : wgs + wg;
+    return (int64_t)local_group * wgs + wg;
 }
 __device__ __forceinline__ int64_t queue_take(char *smem, unsigned int *gqueue, int lane)
 {
@@ -321,11 +325,11 @@ __device__ __forceinline__ int64_t queue_take(char *smem, unsigned int *gqueue, 
         if (lane == 0)
             t = atomicAdd(gqueue, 1u);
         t = __builtin_amdgcn_readfirstlane(t);
-        const unsigned long long e = ((unsigned long long)(2u * gridDim.x + t) << 32) | (unsigned long long)(g + 2u);
+        const unsigned long long e = ((unsigned long long)(Q_AHEAD * gridDim.x + t) << 32) | (unsigned long long)(g + Q_AHEAD);
         if (lane == 0)
-            __hip_atomic_store(&ring[(g + 2u) & (Q_RING - 1)], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&ring[(g + Q_AHEAD) & (Q_RING - 1)], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // the entry of group g was published by the taker of slot 0 of group g - 2 (or at kernel start): it is almost
+    // the entry of group g was published by the taker of slot 0 of group g - Q_AHEAD (or at kernel start): it is almost
     // always there already; its writer waits for nothing but its own global atomic, so this loop ends
     unsigned long long e;
     for (;;)
@@ -418,11 +422,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         f4v_t *dst = reinterpret_cast<f4v_t *>(smem);
         for (int i = threadIdx.x; i < LDS_XB / 16; i += 512)
             dst[i] = src[i];
-        // block queue: slot counter 0; local groups 0 and 1 are static, the rest of the ring is empty
+        // block queue: slot counter 0; the first local group(s) are static, the rest of the ring is empty
         if (threadIdx.x < Q_RING)
         {
             unsigned long long e = ~0ull;
-            if (threadIdx.x < 2)
+            if (threadIdx.x < Q_AHEAD)
                 e = ((unsigned long long)fft_static_group(threadIdx.x, blockIdx.x, gridDim.x) << 32) | threadIdx.x;
             reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16)[threadIdx.x] = e;
         }
@@ -878,15 +882,15 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 }
 
 // Host view of the block queue (see queue_take): groups of FFT_WAVES blocks in global order; workgroup b starts with
-// global groups b and wgs + b (static), every further group of a workgroup is global group 2 * wgs + ticket.  Tickets
-// keep being drawn past the end (a wave learns that it is done by receiving a block >= nblocks), at most one per group
-// slot 0 taken, so a launch draws fewer than groups + 2 * wgs of them; the counter is re-zeroed by the launch before.
+// global group b (static), every further group of a workgroup is global group wgs + ticket.  Tickets keep being drawn
+// past the end (a wave learns that it is done by receiving a block >= nblocks), at most one per group slot 0 taken, so a
+// launch draws fewer than groups + 2 * wgs of them; the counter is re-zeroed by the launch before.
 void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s)
 {
     const int64_t groups = (nblocks + FFT_WAVES - 1) / FFT_WAVES;
     s.RA = FFT_WAVES; // blocks per group
     s.nA = groups;
-    s.RB = 2;         // static groups per workgroup
+    s.RB = Q_AHEAD;   // static groups per workgroup = groups fetched ahead
     s.nB = 0;
     s.wgs = groups < wgs_max ? groups : wgs_max;
     if (s.wgs < 1)

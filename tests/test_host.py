@@ -179,9 +179,9 @@ def test_overlap_save_tables_refuse_unsupported(fir):
 
 def test_overlap_save_block_queue_hands_out_every_block_once(fir):
     """The two-level block queue of the overlap-save kernel (host mirror of queue_take() in if_fir_fft.hip): a workgroup's
-    slot s is block s % 8 of its local group s // 8; local groups 0 and 1 are the static global groups b and wgs + b,
-    local group g >= 2 is global group 2 * wgs + ticket, the ticket drawn from the launch's counter by whoever takes
-    slot 0 of local group g - 2.  Whatever the interleaving of the workgroups' takes, every block in [0, nblocks) is
+    slot s is block s % 8 of its local group s // 8; the first `ahead` local groups are static (global groups b,
+    wgs + b, ...), local group g >= ahead is global group ahead * wgs + ticket, the ticket drawn from the launch's
+    counter by whoever takes slot 0 of local group g - ahead (ahead = 1: a workgroup holds at most one unstarted group).  Whatever the interleaving of the workgroups' takes, every block in [0, nblocks) is
     handed out exactly once, a wave stops at its first block >= nblocks, and the counter stays below the bound the
     launcher reports."""
     rng = np.random.default_rng(5)
@@ -190,13 +190,13 @@ def test_overlap_save_block_queue_hands_out_every_block_once(fir):
     for nblocks in sizes:
         for wgs_max in (1, 2, 3, 8, 256, 304):
             s = fir.debug_fft_schedule(nblocks, wgs_max)
-            assert s["RA"] == 8 and s["nA"] == (nblocks + 7) // 8 and s["RB"] == 2
-            wgs = s["wgs"]
+            assert s["RA"] == 8 and s["nA"] == (nblocks + 7) // 8 and s["RB"] in (1, 2)
+            wgs, ahead = s["wgs"], s["RB"]
             assert 1 <= wgs <= wgs_max and wgs <= s["nA"]
             counter = 0
             seen = np.zeros(nblocks, dtype=np.int32)
             slots = [0] * wgs                       # LDS slot counter per workgroup
-            ring = [{0: b, 1: wgs + b} for b in range(wgs)]
+            ring = [{k: k * wgs + b for k in range(ahead)} for b in range(wgs)]
             live = [8] * wgs                        # waves still running per workgroup
             order = list(range(wgs))
             while any(live):
@@ -205,7 +205,7 @@ def test_overlap_save_block_queue_hands_out_every_block_once(fir):
                 slots[b] += 1
                 g, j = divmod(sl, 8)
                 if j == 0:
-                    ring[b][g + 2] = 2 * wgs + counter
+                    ring[b][g + ahead] = ahead * wgs + counter
                     counter += 1
                 blk = ring[b][g] * 8 + j
                 if blk >= nblocks:
