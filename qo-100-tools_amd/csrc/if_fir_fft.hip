@@ -566,13 +566,19 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     r[4 * j + rho] = t[j];
                 else
                 {
+#ifdef IF_FIR_DIAG_NO_TW // (timing study builds only: twiddles from registers instead of LDS, results wrong)
+                    const f2v w = {0.6f, 0.8f};
+#else
                     const f2v w = tw1[(rho * 16 + j) * 64 + lane];
+#endif
                     r[4 * j + rho] = cmul_v<false>(t[j], w);
                 }
             }
         }
         FFT_STAMP(2);
+#ifndef IF_FIR_DIAG_NO_X1 // (timing study builds only: results are wrong without the exchange)
         exchange1_fwd(r);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
@@ -588,7 +594,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     r[phys(i, j)] = t[j];
                 else
                 {
+#ifdef IF_FIR_DIAG_NO_TW
+                    const f2v w = {0.6f, 0.8f};
+#else
                     const f2v w = tw2[j * 16 + (lane & 15)];
+#endif
                     r[phys(i, j)] = cmul_v<false>(t[j], w);
                 }
             }
