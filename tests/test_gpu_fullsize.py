@@ -208,3 +208,62 @@ def test_beyond_32_bit_offsets(fir, oracle, gpu_ok):
         step = 1 << 28
         worst = max((y[a:a + step] - yd[a:a + step]).abs().max().item() for a in range(0, y.numel(), step))
         assert worst <= 2e-6 * scale, worst / scale
+
+
+@pytest.mark.parametrize("t,d", [(4095, 1), (4095, 4)])
+def test_full_size_two_partition_filter(fir, oracle, gpu_ok, t, d):
+    """3074..4096 taps (two partitions, accumulating second launch) on 2^25 samples: every output against the tap-split
+    kernel (another algorithm: time-domain MACs), windows against the float64 oracle, the unit impulse returns the taps,
+    and a split at a multiple of the block advance is bit-identical to the unsplit call (history = 4096 samples)."""
+    import torch
+    torch.cuda.set_device(0)
+    n = 1 << 25
+    taps = fir.bpf_design(t)
+    with fir.IfFir(taps, d, 0) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+        m = f.out_count(n)
+        y = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        f.synth_device(x.data_ptr(), 0, n, 3)
+        assert f.process_device(x.data_ptr(), y.data_ptr(), n) == m
+        f.synchronize()
+        scale = float(y.abs().max().item())
+        for start in [0, 2048 - 16, 4096, (n // 3) & ~3, n - 8192]:
+            w = 8192
+            lo = max(0, start - (t - 1))
+            xs = x[2 * lo:2 * (start + w)].cpu().numpy()
+            hist = np.zeros(2 * (t - 1), dtype=np.float32)
+            hist[2 * (t - 1 - (start - lo)):] = xs[:2 * (start - lo)]
+            ref = oracle.fir_f64(taps, xs[2 * (start - lo):], d, hist, start)
+            first_out = (start + d - 1) // d
+            got = y[2 * first_out:2 * first_out + ref.size].cpu().numpy()
+            l2, mx = oracle.err_metrics(got, ref)
+            assert l2 <= 1e-6 and mx <= 1e-6, (start, l2, mx)
+        # split at 300 block advances of the 32-row kernel (2048 samples each): same blocks, same bits
+        cut = 300 * 2048 * 8
+        y2 = torch.empty_like(y)
+        f.reset()
+        m1 = f.process_device(x.data_ptr(), y2.data_ptr(), cut)
+        m2 = f.process_device(x.data_ptr() + 8 * cut, y2.data_ptr() + 8 * m1, n - cut)
+        f.synchronize()
+        assert m1 + m2 == m and torch.equal(y, y2)
+        # another algorithm on the whole array
+        yt = torch.empty_like(y)
+        f.set_backend(fir.BACKEND_HIP_TAPSPLIT)
+        f.reset()
+        assert f.process_device(x.data_ptr(), yt.data_ptr(), n) == m
+        f.synchronize()
+        assert float((y - yt).abs().max().item()) <= 2e-6 * scale
+        # impulse response
+        f.set_backend(fir.BACKEND_HIP_FFT)
+        f.reset()
+        x[:2 * 16384].zero_()
+        x[2 * 5] = 1.0
+        f.process_device(x.data_ptr(), y.data_ptr(), 16384)
+        f.synchronize()
+        got = y[:2 * (16384 // d)].cpu().numpy()
+        full = np.zeros(16384, dtype=np.float64)
+        full[5:5 + t] = taps
+        want = full[::d][:got.size // 2]
+        assert np.max(np.abs(got[0::2] - want)) <= 1e-6 * np.max(np.abs(taps)) and np.max(np.abs(got[1::2])) <= 1e-6 * np.max(np.abs(taps))
