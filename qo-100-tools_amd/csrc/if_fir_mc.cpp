@@ -14,6 +14,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -49,10 +50,12 @@ RcclApi *rccl()
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib)
         return &g_rccl;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // IF_FIR_RCCL_LIBRARY: an explicit library path (another RCCL build; the tests load an in-process stand-in for the
+    // transport here, tests/c/fake_rccl.cpp, to run several ranks as threads on one GPU)
+    const char *names[] = {getenv("IF_FIR_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
     for (const char *n : names)
-        if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
+        if (n && *n && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
             break;
     if (!lib)
     {

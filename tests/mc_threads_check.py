@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""mc_threads_check.py <fake_rccl.so> <world> <channels> — runs the multi-rank path of if_fir_mc_* on ONE GPU with the
+ranks as threads of this process and tests/c/fake_rccl.cpp as the transport (IF_FIR_RCCL_LIBRARY).  Everything of
+if_fir_mc_process_device executes as on a multi-GPU node — the transfer plan, chunking, the transfer and filter streams,
+their events, the status word — except that a "link" is a device-to-device copy.  Rank 0 checks every channel's output
+bit for bit against a single-channel context fed the same calls.  Started as a subprocess by tests/test_mc_threads.py
+(the library caches the RCCL entry points per process)."""
+import os
+import sys
+import threading
+
+fake, world, channels = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+os.environ["IF_FIR_RCCL_LIBRARY"] = fake
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import __graft_entry__ as g  # noqa: E402
+
+fir = g.load_pkg().if_fir
+torch.cuda.set_device(0)
+d, t = 4, 255
+calls = [700_000, 300_004]                      # two calls: streaming state per channel, phase 0 at every chunk boundary
+nmax = max(calls)
+taps = np.stack([fir.bpf_design(t, 0.02 + 0.04 * c, 0.05 + 0.04 * c) for c in range(channels)])
+uid = fir.mc_unique_id()
+assert uid.startswith(b"fake-rccl-world-"), "the stand-in transport was not loaded"
+with fir.IfFir(taps[0], d, 0) as f:
+    ins = [[torch.empty(2 * n, dtype=torch.float32, device="cuda") for _ in range(channels)] for n in calls]
+    first = 0
+    for k, n in enumerate(calls):
+        for c in range(channels):
+            f.synth_device(ins[k][c].data_ptr(), first, n, c)
+        first += n
+    f.synchronize()
+outs = [[torch.zeros(2 * ((n + d - 1) // d) + 8, dtype=torch.float32, device="cuda") for _ in range(channels)] for n in calls]
+torch.cuda.synchronize()
+errors, counts = [], {}
+barrier = threading.Barrier(world)
+
+
+def rank_main(rank):
+    try:
+        torch.cuda.set_device(0)
+        with fir.IfFirMc(taps, d, nmax, device=0, rank=rank, world=world, unique_id=uid) as mc:
+            mc.set_chunk_samples(fir.MC_CHUNK_UNIT)        # 215040 samples: four chunks in the first call, two in the second
+            for k, n in enumerate(calls):
+                barrier.wait()
+                m = mc.process_device([x.data_ptr() for x in ins[k]] if rank == 0 else None,
+                                      [y.data_ptr() for y in outs[k]] if rank == 0 else None, n)
+                counts[(rank, k)] = m
+    except Exception as e:   # noqa: BLE001
+        errors.append("rank %d: %r" % (rank, e))
+        try:
+            barrier.abort()
+        except Exception:   # noqa: BLE001
+            pass
+
+
+threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+for th in threads:
+    th.start()
+for th in threads:
+    th.join(timeout=120)
+if any(th.is_alive() for th in threads):
+    print("FAIL: a rank did not return within 120 s")
+    os._exit(3)
+if errors:
+    print("FAIL:", "; ".join(errors))
+    sys.exit(1)
+ok = True
+for c in range(channels):
+    with fir.IfFir(taps[c], d, 0) as f:
+        for k, n in enumerate(calls):
+            ref = torch.empty(2 * f.out_count(n), dtype=torch.float32, device="cuda")
+            m = f.process_device(ins[k][c].data_ptr(), ref.data_ptr(), n)
+            f.synchronize()
+            got = outs[k][c]
+            same = bool(torch.equal(ref, got[:2 * m])) and bool((got[2 * m:] == 0).all())
+            if not same or any(counts[(r, k)] != m for r in range(world)):
+                ok = False
+                print("channel %d (rank %d) call %d: MISMATCH (max |diff| %g, counts %s)" %
+                      (c, c % world, k, (ref - got[:2 * m]).abs().max().item(), [counts[(r, k)] for r in range(world)]))
+print("%d ranks as threads, %d channels, calls %s, chunks of %d samples: %s" %
+      (world, channels, calls, fir.MC_CHUNK_UNIT, "all channels bit-identical to single-channel contexts" if ok else "FAIL"))
+sys.exit(0 if ok else 1)

@@ -1,0 +1,28 @@
+"""GPU test: the multi-rank path of if_fir_mc_* EXECUTED on one GPU — ranks as threads, tests/c/fake_rccl.cpp as the
+transport (RCCL refuses two ranks on one device).  See tests/mc_threads_check.py."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fake_rccl(gpu_ok):
+    tmp = tempfile.mkdtemp(prefix="fake_rccl_")
+    so = os.path.join(tmp, "libfake_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17", "-x", "hip",
+                           os.path.join(ROOT, "tests", "c", "fake_rccl.cpp"), "-o", so])
+    return so
+
+
+@pytest.mark.parametrize("world,channels", [(2, 3), (3, 5), (4, 4), (4, 2)])
+def test_ranks_as_threads_match_single_channel_contexts(fake_rccl, world, channels):
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mc_threads_check.py"), fake_rccl, str(world), str(channels)],
+                         capture_output=True, text=True, timeout=400)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert "bit-identical" in run.stdout

@@ -25,19 +25,37 @@ def main():
     n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 24)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # IF_FIR_MC_SAME_DEVICE=1: every rank on GPU 0 and the bootstrap id over gloo -- an attempt to run the rank-to-rank
+    # path on a one-GPU box (RCCL may refuse two ranks on one device; then this prints its error and exits 2)
+    same_device = os.environ.get("IF_FIR_MC_SAME_DEVICE") == "1"
+    if same_device:
+        local = 0
     torch.cuda.set_device(local)
     fir = g.load_pkg().if_fir
     uid = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        idt = torch.zeros(fir.MC_ID_BYTES, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt = torch.frombuffer(bytearray(fir.mc_unique_id()), dtype=torch.uint8).cuda()
-        dist.broadcast(idt, 0)
-        uid = bytes(idt.cpu().numpy().tobytes())
+        if same_device:
+            dist.init_process_group("gloo")
+            idt = torch.zeros(fir.MC_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(fir.mc_unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(idt, 0)
+            uid = bytes(idt.numpy().tobytes())
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            idt = torch.zeros(fir.MC_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(fir.mc_unique_id()), dtype=torch.uint8).cuda()
+            dist.broadcast(idt, 0)
+            uid = bytes(idt.cpu().numpy().tobytes())
     d, t = 4, 255
     taps = np.stack([fir.bpf_design(t, 0.02 + 0.05 * c, 0.06 + 0.05 * c) for c in range(channels)])
-    with fir.IfFirMc(taps, d, n, device=local, rank=rank, world=world, unique_id=uid) as mc:
+    try:
+        mc_ctx = fir.IfFirMc(taps, d, n, device=local, rank=rank, world=world, unique_id=uid)
+    except fir.IfFirError as e:
+        print("rank %d: if_fir_mc_init failed: %s" % (rank, e), flush=True)
+        sys.exit(2)
+    with mc_ctx as mc:
         ins = outs = None
         if rank == 0:
             with fir.IfFir(taps[0], d, 0, device=local) as f:
