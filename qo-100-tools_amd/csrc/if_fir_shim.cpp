@@ -395,7 +395,7 @@ IF_FIR_API uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant)
         return 0;
     // 1000..1999 are diagnostic launches of the overlap-save kernel that skip loads or stores (WRONG results, for
     // timing studies): refused unless the process runs with IF_FIR_DEBUG=1.  Everything else changes speed only.
-    if (ulVariant >= 1000 && ulVariant < 2000 && !debug_enabled())
+    if (((ulVariant >= 1000 && ulVariant < 2000) || ulVariant == 4000) && !debug_enabled())
     {
         set_err(pCtx, "if_fir_set_tuning: variant %u is a diagnostic launch (wrong results); set IF_FIR_DEBUG=1 to allow it",
                 ulVariant);
@@ -456,6 +456,14 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     if (n > (uint64_t)1 << 40)
     {
         set_err(ctx, "if_fir_process_device: sample count too large");
+        return 0;
+    }
+    if (ctx->variant == 4000 && debug_enabled())
+    {
+        // test hook (IF_FIR_DEBUG=1 only): the next call fails before anything is launched -- lets the tests exercise the
+        // error paths of callers (the multi-channel front's status word) without breaking a device
+        ctx->variant = 0;
+        set_err(ctx, "if_fir_process_device: injected failure (tuning variant 4000, test hook)");
         return 0;
     }
     if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))

@@ -10,7 +10,9 @@ import sys
 import threading
 
 fake, world, channels = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+inject = len(sys.argv) > 4 and sys.argv[4] == "inject"   # rank 1's first channel fails its first filter call
 os.environ["IF_FIR_RCCL_LIBRARY"] = fake
+os.environ["IF_FIR_DEBUG"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
@@ -36,7 +38,7 @@ with fir.IfFir(taps[0], d, 0) as f:
     f.synchronize()
 outs = [[torch.zeros(2 * ((n + d - 1) // d) + 8, dtype=torch.float32, device="cuda") for _ in range(channels)] for n in calls]
 torch.cuda.synchronize()
-errors, counts = [], {}
+errors, counts, injected = [], {}, {}
 barrier = threading.Barrier(world)
 
 
@@ -45,6 +47,25 @@ def rank_main(rank):
         torch.cuda.set_device(0)
         with fir.IfFirMc(taps, d, nmax, device=0, rank=rank, world=world, unique_id=uid) as mc:
             mc.set_chunk_samples(fir.MC_CHUNK_UNIT)        # 215040 samples: four chunks in the first call, two in the second
+            if inject:
+                # an owner's filter fails in the middle of the protocol: nobody may hang, the owner and the root must both
+                # report it, the others succeed; after a reset on every rank the front works again
+                if rank == 1:
+                    h = mc.channel_ctx(1)
+                    assert h and fir.lib().if_fir_set_tuning(h, 4000)
+                barrier.wait()
+                try:
+                    mc.process_device([x.data_ptr() for x in ins[0]] if rank == 0 else None,
+                                      [y.data_ptr() for y in outs[0]] if rank == 0 else None, calls[0])
+                    injected[rank] = "ok"
+                except fir.IfFirError as e:
+                    injected[rank] = str(e)
+                barrier.wait()
+                mc.reset()
+                for k in range(len(calls)):
+                    for y in outs[k]:
+                        y.zero_() if rank == 0 else None
+                torch.cuda.synchronize()
             for k, n in enumerate(calls):
                 barrier.wait()
                 m = mc.process_device([x.data_ptr() for x in ins[k]] if rank == 0 else None,
@@ -70,6 +91,10 @@ if errors:
     print("FAIL:", "; ".join(errors))
     sys.exit(1)
 ok = True
+if inject:
+    print("injected failure:", injected)
+    ok = ("injected failure" in injected.get(1, "") and "rank 1 reported a filter failure" in injected.get(0, "")
+          and all(injected.get(r) == "ok" for r in range(2, world)))
 for c in range(channels):
     with fir.IfFir(taps[c], d, 0) as f:
         for k, n in enumerate(calls):
