@@ -265,10 +265,6 @@ struct AsmWalk;
     };
 IF_FIR_ASM_WALK(255, 4, 8, 32, 0, walk_asm_T255_D4_R8_S32)
 IF_FIR_ASM_WALK(255, 4, 8, 32, 2, walk_asm_T255_D4_R8_S32_b128)
-IF_FIR_ASM_WALK(255, 1, 8, 32, 0, walk_asm_T255_D1_R8_S32)
-IF_FIR_ASM_WALK(255, 1, 16, 32, 0, walk_asm_T255_D1_R16_S32)
-IF_FIR_ASM_WALK(127, 1, 8, 32, 0, walk_asm_T127_D1_R8_S32)
-IF_FIR_ASM_WALK(127, 1, 16, 32, 0, walk_asm_T127_D1_R16_S32)
 IF_FIR_ASM_WALK(127, 4, 8, 32, 0, walk_asm_T127_D4_R8_S32)
 
 typedef __attribute__((address_space(3))) char lds_char_t;
@@ -770,10 +766,6 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             {
             case 1: return launch_direct<255, 1, 16, 32, 256, false>(a);
             case 2: return launch_direct<255, 1, 8, 32, 256, true>(a);
-            case 3: return launch_wave<255, 1, 16, 32, 0>(a, 4);
-            case 4: return launch_wave<255, 1, 8, 32, 0>(a, 4);
-            case 5: return launch_wave<255, 1, 16, 32, 0>(a, 8);
-            case 6: return launch_wave<255, 1, 16, 32, 0>(a, 2);
             default: return launch_direct<255, 1, 16, 32, 256, true>(a);
             }
         }
@@ -783,10 +775,6 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             {
             case 1: return launch_direct<127, 1, 16, 32, 256, false>(a);
             case 2: return launch_direct<127, 1, 8, 32, 256, true>(a);
-            case 3: return launch_wave<127, 1, 16, 32, 0>(a, 4);
-            case 4: return launch_wave<127, 1, 8, 32, 0>(a, 4);
-            case 5: return launch_wave<127, 1, 16, 32, 0>(a, 8);
-            case 6: return launch_wave<127, 1, 16, 32, 0>(a, 2);
             default: return launch_direct<127, 1, 16, 32, 256, true>(a);
             }
         }

@@ -196,11 +196,9 @@ def emit_function(f, name, lines, clobbers, meta, suffix=""):
 
 CONFIGS = [
     # (T, D, R, SEG, [(suffix, Q, U), ...])
+    # only what the library launches: the decimating walks (the D = 1 wave-kernel walks of round 1 were reachable through
+    # tuning variants only -- the D = 1 configurations run the compiler-scheduled workgroup kernel -- and were removed)
     (255, 4, 8, 32, [("", 4, 1), ("_b128", 2, 2)]),
-    (255, 1, 8, 32, [("", 4, 1)]),
-    (255, 1, 16, 32, [("", 3, 1)]),
-    (127, 1, 8, 32, [("", 4, 1)]),
-    (127, 1, 16, 32, [("", 3, 1)]),
     (127, 4, 8, 32, [("", 4, 1)]),
 ]
 
