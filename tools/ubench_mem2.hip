@@ -99,6 +99,7 @@ __device__ __forceinline__ long unit_of(const MapArgs &m, long it, int j, int wi
     case 0: return it * m.waves + gw;                                  // static, wave-interleaved: compact chip-wide window
     case 1: return (it * m.waves + gw) * m.run + j;                    // static runs of `run` units per wave
     case 2: return it * m.waves + (long)wid * m.wgs + blockIdx.x;      // neighbours of a unit live on other workgroups
+    case 5: return it == 0 ? (long)gw : m.nunits;                      // one shot: one unit per wave, the grid covers the stream
     default:
     {
         const int x = blockIdx.x & 7, wx = (blockIdx.x >> 3) * nw + wid, Wx = m.waves >> 3; // XCD-chunked window
@@ -283,6 +284,19 @@ int main(int argc, char **argv)
         t = time_ms([&]() { hipLaunchKernelGGL(mix41_oneshot<1>, dim3(nout / 256), dim3(256), 0, 0, in, out, nout); }, 9);
         printf("mix 4:1 oneshot nt                         : %.3f ms %.2f TB/s (frac %.3f)\n", t, 1.25 * inb / t / 1e9, 1.25 * inb / t / 8e12 * 1e3);
         fflush(stdout);
+    }
+    if (want("oneshot"))
+    {
+        // the filter's blocks handed out by the hardware dispatcher instead of a persistent grid: one 4096-point block per
+        // wave, 8 waves per workgroup, nunits / 8 workgroups in dispatch order (no tables to reload here; the real
+        // kernel would pay an 82 KB table load per workgroup)
+        const int wgs = (int)((NSAMP * 8 / (32 * 1024 - 2048)) / 8);
+        run_blocks<32, 8, 8, 0, 0, 512, 2>("4k 1shot", wgs, 5, 1);
+        run_blocks<32, 16, 16, 0, 0, 512, 2>("4k 1shot", wgs, 5, 1);
+        run_blocks<32, 16, 16, 2, 2, 512, 2>("4k 1shot ntLS", wgs, 5, 1);
+        run_blocks<32, 8, 8, 0, 0, 512, 2>("4k persist", 256, 0, 1);
+        run_blocks<32, 16, 16, 2, 2, 512, 2>("4k persist ntLS", 256, 0, 1);
+        run_blocks<16, 16, 16, 2, 2, 512, 4>("2k 1shot ntLS", (int)((NSAMP * 8 / (16 * 1024 - 2048)) / 8), 5, 1);
     }
     if (want("blocks"))
     {
