@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, WPS) void fir_direct_wave_kernel(const f2 *__r
                     const int e = 2 * (lane + 64 * i); // output index inside the tile
                     const f4 v = *reinterpret_cast<const f4 *>(wl + G::OUT_OFF + (e / R) * G::OCH + (e % R) * 8);
                     if (full)
-                        *reinterpret_cast<f4 *>(out + m_tile + e) = v;
+                        __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + m_tile + e)); // never read again
                     else
                     {
                         if (m_tile + e < M)
@@ -699,7 +699,7 @@ static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
     constexpr int LDS = 4 * G::WAVE_LDS;
     constexpr int BPC = (160 * 1024) / LDS;                 // workgroups (of 4 waves) per CU by LDS
     static_assert(BPC >= 1, "window too large");
-    constexpr int WPS = BPC >= 2 ? 2 : 1;                   // waves per SIMD the register budget is sized for
+    constexpr int WPS = BPC >= 3 ? 3 : BPC >= 2 ? 2 : 1;    // waves per SIMD the register budget is sized for
     auto kern = fir_direct_wave_kernel<T, D, R, SEG, V, WPS>;
     static DeviceSetup setup;
     int ncus = 0;
@@ -711,7 +711,7 @@ static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
     const int64_t tiles = (a.M + G::TILE_OUT - 1) / G::TILE_OUT;
     if (tiles <= 0)
         return hipSuccess;
-    int64_t blocks = (int64_t)ncus * (BPC > 2 ? 2 : BPC);
+    int64_t blocks = (int64_t)ncus * WPS;
     int64_t waves = blocks * 4;
     int64_t run_len = run_len_arg > 0 ? run_len_arg : 4;
     const int64_t per_wave = (tiles + waves - 1) / waves;

@@ -7,9 +7,9 @@ cp qo-100-tools_amd/libif_fir.so /tmp/libif_fir_base.so
 for r in $(seq 1 $R); do
   for w in "$@"; do
     cp "$A" qo-100-tools_amd/libif_fir.so
-    echo "A $(python tools/sweep.py $w 100 100 100 2>/dev/null | grep variant | tail -1 | cut -c1-60)"
+    echo "A $(python tools/sweep.py $w ${VARIANTS:-100 100 100} 2>/dev/null | grep variant | tail -1 | cut -c1-60)"
     cp /tmp/libif_fir_base.so qo-100-tools_amd/libif_fir.so
-    echo "B $(python tools/sweep.py $w 100 100 100 2>/dev/null | grep variant | tail -1 | cut -c1-60)"
+    echo "B $(python tools/sweep.py $w ${VARIANTS:-100 100 100} 2>/dev/null | grep variant | tail -1 | cut -c1-60)"
   done
 done
 cp /tmp/libif_fir_base.so qo-100-tools_amd/libif_fir.so
