@@ -224,9 +224,18 @@ def time_config(fir, name, backend, x, dev, stream, steps, warmup, names):
     with fir.IfFir(taps, decim, 0, device=dev.index, backend=backend) as fc:
         fc.set_stream(stream.cuda_stream)
         y = torch.empty(2 * fc.out_count(n), dtype=torch.float32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
         for _ in range(warmup):
             fc.process_device(x.data_ptr(), y.data_ptr(), n)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        # a kernel's rate settles only after ~100 ms of ITS OWN launches (power management): keep going for that long
+        # when a launch is short (the 34 ms tap-split launches are not repeated for this)
+        per = e0.elapsed_time(e1) / max(warmup, 1)
+        if per < 5.0:
+            for _ in range(int(min(400, 100.0 / max(per, 0.05)))):
+                fc.process_device(x.data_ptr(), y.data_ptr(), n)
         e0.record(stream)
         for _ in range(steps):
             fc.process_device(x.data_ptr(), y.data_ptr(), n)
@@ -360,20 +369,39 @@ def main():
     # After idling, the chip's power management first boosts, then clamps the clock hard for ~20 launches (10 ms) and
     # only then settles (profiles/r02a_kernel_trace_summary.json: 0.48-0.52 ms, then 0.60-0.67 ms, then 0.49 ms per
     # launch).  A filter in service streams continuously, so `value` is the settled rate: every rank first keeps its
-    # GPU busy for >= --condition-ms of device time with the other things this script measures anyway (direct form,
-    # the other BASELINE configs, a plain copy: reported under "extra", never part of `value`) and, where those do not
-    # run, with untimed passes of the very same step.  The W warm-up steps and the K timed steps follow unchanged.
+    # GPU busy for >= --condition-ms of device time: untimed passes of the very same step, then the other things this
+    # script measures anyway (direct form, the other BASELINE configs, a plain copy: reported under "extra", never part
+    # of `value`, and settled as well this way), then passes of the step again.  The W warm-up steps and the K timed
+    # steps follow unchanged.
     extra = {}
     names = {1: "hip_direct", 2: "hip_tapsplit", 3: "hip_generic", 4: "hip_fft"}
     cond0 = torch.cuda.Event(enable_timing=True)
     cond0.record(stream)
+    cond_passes = 0
+    cond1 = torch.cuda.Event(enable_timing=True)
+
+    def condition(until_ms, min_passes):
+        # untimed passes of the very same step until `until_ms` of device time have passed since cond0
+        nonlocal cond_passes
+        done = 0
+        while args.condition_ms > 0 and cond_passes < 100000:
+            cond1.record(stream)
+            torch.cuda.synchronize()
+            if cond0.elapsed_time(cond1) >= until_ms and done >= min_passes:
+                break
+            for _ in range(20):
+                step_stream()
+            cond_passes += 20
+            done += 20
+
+    condition(args.condition_ms / 2, 20)   # first half ahead of the comparison measurements: they run settled as well
     if args.backend == "auto" and f.get_backend() == fir.BACKEND_HIP_FFT and taps_n in (127, 255) \
             and decim in (1, 4) and not i16 and not nco:
         # the north_star's direct-form MAC kernel, timed beside the default overlap-save path (same buffers, same
         # stream; not part of `value`)
         f.set_backend(fir.BACKEND_HIP_DIRECT)
         f.reset()
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 100)):   # ~100 ms of its own launches: settled like the headline
             step_stream()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -425,18 +453,10 @@ def main():
         except Exception as e:   # noqa: BLE001 - context only, never fatal
             cfgs["error"] = repr(e)
         extra["configs"] = cfgs
-    cond1 = torch.cuda.Event(enable_timing=True)
+    condition(args.condition_ms, 20)       # and passes of the step itself right in front of the warm-up
     cond1.record(stream)
     torch.cuda.synchronize()
     conditioning_ms = cond0.elapsed_time(cond1)
-    cond_passes = 0
-    while (conditioning_ms < args.condition_ms or cond_passes < 20) and cond_passes < 100000 and args.condition_ms > 0:
-        for _ in range(20):
-            step_stream()
-        cond_passes += 20
-        cond1.record(stream)
-        torch.cuda.synchronize()
-        conditioning_ms = cond0.elapsed_time(cond1)
 
     for _ in range(args.warmup):
         step_stream()
