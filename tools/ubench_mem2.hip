@@ -90,6 +90,8 @@ __global__ __launch_bounds__(256) void mix41_oneshot(const f4 *__restrict__ in, 
 // FFT-block shaped streaming.  NR16 = KiB per block (32: 4096 samples, 16: 2048 samples); the block starts OVLB bytes
 // before its unit (overlap re-read); unit = NR16*1024 - 2048 bytes of new input, a quarter of that is written.
 struct MapArgs { long nunits; int waves; int map; int run; int wgs; };
+// FLAGS (template): 1 = the waves of a workgroup move in lockstep (s_barrier per unit), 2 = the stores of a unit go out
+// ahead of the next unit's loads
 
 __device__ __forceinline__ long unit_of(const MapArgs &m, long it, int j, int wid, int nw)
 {
@@ -108,7 +110,7 @@ __device__ __forceinline__ long unit_of(const MapArgs &m, long it, int j, int wi
     }
 }
 
-template <int NR16, int LW, int SW, int LAUX, int SAUX, int WG, int MINW>
+template <int NR16, int LW, int SW, int LAUX, int SAUX, int WG, int MINW, int FLAGS = 0>
 __global__ __launch_bounds__(WG, MINW) void k_blocks(const char *__restrict__ in, char *__restrict__ out, MapArgs m)
 {
     constexpr int BLKB = NR16 * 1024, OVLB = 2048, UB = BLKB - OVLB, OB = UB / 4;
@@ -163,9 +165,12 @@ __global__ __launch_bounds__(WG, MINW) void k_blocks(const char *__restrict__ in
         if (j >= runlen) { j = 0; it++; }
         un = unit_of(m, it, j, wid, nw);
         const bool more = un < m.nunits;
-        issue_loads(un, more);
+        if (FLAGS & 1)
+            __builtin_amdgcn_s_barrier();
+        if (!(FLAGS & 2))
+            issue_loads(un, more);
         __builtin_amdgcn_sched_barrier(0);
-        // stores of the current unit behind the next unit's loads
+        // stores of the current unit behind the next unit's loads (flags & 2: ahead of them)
         const srd_t osrd = make_srd(out + u * OB, OB);
         if (SW == 16)
         {
@@ -189,6 +194,11 @@ __global__ __launch_bounds__(WG, MINW) void k_blocks(const char *__restrict__ in
                 u2 w = {__float_as_uint(st[r].x), __float_as_uint(st[r].y)};
                 __builtin_amdgcn_raw_buffer_store_b64(w, osrd, lane * 8u, r * 512, SAUX);
             }
+        }
+        if (FLAGS & 2)
+        {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_loads(un, more);
         }
         u = un;
         have = more;
@@ -218,7 +228,7 @@ template <typename F> static float time_ms(F launch, int reps)
 static char *g_in, *g_out;
 static const size_t NSAMP = (size_t)1 << 28;
 
-template <int NR16, int LW, int SW, int LAUX, int SAUX, int WG, int MINW>
+template <int NR16, int LW, int SW, int LAUX, int SAUX, int WG, int MINW, int FLAGS = 0>
 static void run_blocks(const char *tag, int wgs, int map, int run)
 {
     constexpr long UB = NR16 * 1024 - 2048;
@@ -226,7 +236,7 @@ static void run_blocks(const char *tag, int wgs, int map, int run)
     m.nunits = (long)(NSAMP * 8 / UB);
     m.waves = wgs * (WG / 64);
     m.map = map; m.run = run; m.wgs = wgs;
-    auto kern = k_blocks<NR16, LW, SW, LAUX, SAUX, WG, MINW>;
+    auto kern = k_blocks<NR16, LW, SW, LAUX, SAUX, WG, MINW, FLAGS>;
     const float t = time_ms([&]() { hipLaunchKernelGGL(kern, dim3(wgs), dim3(WG), 0, 0, g_in, g_out, m); }, 9);
     const double alg = (double)m.nunits * UB * 1.25;
     hipFuncAttributes fa;
@@ -297,6 +307,20 @@ int main(int argc, char **argv)
         run_blocks<32, 8, 8, 0, 0, 512, 2>("4k persist", 256, 0, 1);
         run_blocks<32, 16, 16, 2, 2, 512, 2>("4k persist ntLS", 256, 0, 1);
         run_blocks<16, 16, 16, 2, 2, 512, 4>("2k 1shot ntLS", (int)((NSAMP * 8 / (16 * 1024 - 2048)) / 8), 5, 1);
+    }
+    if (want("shape"))
+    {
+        // what makes the dispatcher-ordered launch faster than the persistent grid?  lockstep workgroups / stores first
+        const int wgs1 = (int)((NSAMP * 8 / (32 * 1024 - 2048)) / 8);
+        run_blocks<32, 16, 16, 2, 2, 512, 2>("1shot", wgs1, 5, 1);
+        run_blocks<32, 16, 16, 2, 2, 512, 2>("persist", 256, 0, 1);
+        run_blocks<32, 16, 16, 2, 2, 512, 2, 1>("persist lockstep", 256, 0, 1);
+        run_blocks<32, 16, 16, 2, 2, 512, 2, 2>("persist st-first", 256, 0, 1);
+        run_blocks<32, 16, 16, 2, 2, 512, 2, 3>("persist lock+stf", 256, 0, 1);
+        run_blocks<32, 8, 8, 2, 2, 512, 2>("persist 8B", 256, 0, 1);
+        run_blocks<32, 8, 8, 2, 2, 512, 2, 1>("persist 8B lock", 256, 0, 1);
+        run_blocks<32, 8, 8, 2, 2, 512, 2, 2>("persist 8B stf", 256, 0, 1);
+        run_blocks<32, 8, 8, 2, 2, 512, 2>("1shot 8B", wgs1, 5, 1);
     }
     if (want("blocks"))
     {
