@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void mix41_oneshot(const f4 *__restrict__ in, 
 // ---------------------------------------------------------------------------------------------------------------
 // FFT-block shaped streaming.  NR16 = KiB per block (32: 4096 samples, 16: 2048 samples); the block starts OVLB bytes
 // before its unit (overlap re-read); unit = NR16*1024 - 2048 bytes of new input, a quarter of that is written.
-struct MapArgs { long nunits; int waves; int map; int run; int wgs; };
+struct MapArgs { long nunits; int waves; int map; int run; int wgs; unsigned *queue; };
+// map 6 / 7: blocks in GLOBAL order from 8 counters (one per blockIdx & 7, 256 B apart), one ticket per block, fetched one
+// block ahead: consecutive blocks go to whichever waves ask next anywhere on the chip (6: singly, 7: in pairs per counter)
 // FLAGS (template): 1 = the waves of a workgroup move in lockstep (s_barrier per unit), 2 = the stores of a unit go out
 // ahead of the next unit's loads
 
@@ -123,7 +125,20 @@ __global__ __launch_bounds__(WG, MINW) void k_blocks(const char *__restrict__ in
     f2 st[NST8 + 1];
     const int runlen = m.map == 1 ? m.run : 1;
     bool have = false;
-    long u = unit_of(m, 0, 0, wid, nw);
+    const bool dyn = m.map >= 6;
+    unsigned *qc = m.queue + (blockIdx.x & 7) * 64;
+    auto ticket_unit = [&](unsigned t) -> long {
+        const long x = blockIdx.x & 7;
+        return m.map == 6 ? (long)t * 8 + x : (long)(t >> 1) * 16 + 2 * x + (t & 1);
+    };
+    unsigned tk = 0, tk_next = 0;
+    if (dyn)
+    {
+        if (lane == 0) tk = atomicAdd(qc, 1u);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (lane == 0) tk_next = atomicAdd(qc, 1u);   // one block ahead; read at the next iteration
+    }
+    long u = dyn ? ticket_unit(tk) : unit_of(m, 0, 0, wid, nw);
     long it = 0;
     int j = 0;
     auto issue_loads = [&](long uu, bool valid) { // an invalid unit reads zeros through an empty descriptor (no branch)
@@ -164,6 +179,11 @@ __global__ __launch_bounds__(WG, MINW) void k_blocks(const char *__restrict__ in
         j++;
         if (j >= runlen) { j = 0; it++; }
         un = unit_of(m, it, j, wid, nw);
+        if (dyn)
+        {
+            un = ticket_unit(__builtin_amdgcn_readfirstlane(tk_next));
+            if (lane == 0) tk_next = atomicAdd(qc, 1u);
+        }
         const bool more = un < m.nunits;
         if (FLAGS & 1)
             __builtin_amdgcn_s_barrier();
@@ -226,6 +246,7 @@ template <typename F> static float time_ms(F launch, int reps)
 }
 
 static char *g_in, *g_out;
+static unsigned *g_queue;
 static const size_t NSAMP = (size_t)1 << 28;
 
 template <int NR16, int LW, int SW, int LAUX, int SAUX, int WG, int MINW, int FLAGS = 0>
@@ -235,9 +256,9 @@ static void run_blocks(const char *tag, int wgs, int map, int run)
     MapArgs m;
     m.nunits = (long)(NSAMP * 8 / UB);
     m.waves = wgs * (WG / 64);
-    m.map = map; m.run = run; m.wgs = wgs;
+    m.map = map; m.run = run; m.wgs = wgs; m.queue = g_queue;
     auto kern = k_blocks<NR16, LW, SW, LAUX, SAUX, WG, MINW, FLAGS>;
-    const float t = time_ms([&]() { hipLaunchKernelGGL(kern, dim3(wgs), dim3(WG), 0, 0, g_in, g_out, m); }, 9);
+    const float t = time_ms([&]() { if (map >= 6) CHECK(hipMemsetAsync(g_queue, 0, 8 * 256, 0)); hipLaunchKernelGGL(kern, dim3(wgs), dim3(WG), 0, 0, g_in, g_out, m); }, 9);
     const double alg = (double)m.nunits * UB * 1.25;
     hipFuncAttributes fa;
     CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
@@ -254,6 +275,7 @@ int main(int argc, char **argv)
     CHECK(hipMemset(g_in, 1, inb + (1 << 20)));
     CHECK(hipMemset(g_out, 0, outb + (1 << 20)));
     g_in += 4096; // blocks start OVLB before their unit
+    CHECK(hipMalloc(&g_queue, 8 * 256));
     const bool all = argc < 2;
     const char *sel = all ? "" : argv[1];
     auto want = [&](const char *s) { return all || strstr(sel, s); };
@@ -321,6 +343,12 @@ int main(int argc, char **argv)
         run_blocks<32, 8, 8, 2, 2, 512, 2, 1>("persist 8B lock", 256, 0, 1);
         run_blocks<32, 8, 8, 2, 2, 512, 2, 2>("persist 8B stf", 256, 0, 1);
         run_blocks<32, 8, 8, 2, 2, 512, 2>("1shot 8B", wgs1, 5, 1);
+        // blocks in global order from sharded per-block tickets (8 counters)
+        run_blocks<32, 8, 8, 2, 2, 512, 2>("persist 8B gq1", 256, 6, 1);
+        run_blocks<32, 8, 8, 2, 2, 512, 2>("persist 8B gq2", 256, 7, 1);
+        run_blocks<32, 16, 16, 2, 2, 512, 2>("persist gq1", 256, 6, 1);
+        run_blocks<32, 16, 16, 2, 2, 512, 2>("persist gq2", 256, 7, 1);
+        run_blocks<32, 8, 8, 2, 2, 512, 2>("persist 8B", 256, 0, 1);
     }
     if (want("blocks"))
     {
