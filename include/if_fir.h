@@ -98,8 +98,13 @@ uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat);
  * set since the last reset (the phase is a function of the absolute index).  Overlap-save and generic kernels only. */
 uint8_t if_fir_set_nco(if_fir_ctx_t *pCtx, double dFreq);
 uint8_t if_fir_get_nco(const if_fir_ctx_t *pCtx, double *pdFreq);
-/* expert knob: pick a tuning variant of the resolved backend's kernel (0 = default).  Also settable
- * with the environment variable IF_FIR_VARIANT read at if_fir_init. */
+/* expert knob: pick a tuning variant of the resolved backend's kernel (0 = default).  Variants change
+ * speed only (1..9: schedules of the direct kernels, 2000 + k: at most k workgroups for the overlap-save kernel).
+ * Development switches are closed unless the process runs with IF_FIR_DEBUG=1: 1000..1999 (diagnostic launches that skip
+ * loads or stores: WRONG results), 4000 (the next call fails: test hook), and the IF_FIR_VARIANT environment variable
+ * read at if_fir_init.
+ * Environment: IF_FIR_RCCL_LIBRARY = path of the library providing the nccl* entry points of the multi-channel front
+ * (default: librccl.so.1 by name). */
 uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant);
 /* (calls on a stream that is being captured into a hipGraph are refused: the streaming state advances on the host) */
 /* run on a caller-owned HIP stream (pass a hipStream_t as void*; NULL = the context's own stream) */
