@@ -195,7 +195,11 @@ uint8_t if_fir_mc_reset(if_fir_mc_ctx_t *pCtx);
 /* all channels take IF_FIR_INPUT_F32 or IF_FIR_INPUT_I16 samples (every rank must make the same call) */
 uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ulFormat);
 /* rank 0: ppDevIn[c] / ppDevOut[c] = device pointers on rank 0's GPU for every channel; other ranks may pass NULL.
- * Synchronous: returns when this rank's part (transfers and filters) has finished.  *pullOutSamples: per channel. */
+ * Synchronous: returns when this rank's part (transfers and filters) has finished.  *pullOutSamples: per channel.
+ * A failing filter on any rank makes the call fail on that rank AND on rank 0 (the other ranks complete normally; the
+ * transfer protocol is always run to its end, nobody is left waiting); the channel streams are then out of step:
+ * call if_fir_mc_reset() on every rank before the next call.  After an RCCL failure the communicator is aborted and the
+ * context refuses further calls (destroy it and create a new one). */
 uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDevIn, void *const *ppDevOut,
                                  uint64_t ullSamples, uint64_t *pullOutSamples);
 /* chunk length of the following calls: 0 = default (16 773 120 samples), UINT64_MAX = never split, otherwise a multiple of
