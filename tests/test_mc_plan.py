@@ -109,3 +109,19 @@ def test_plan_rejects_bad_arguments_and_single_rank_moves_nothing(fir):
     assert fir.lib().if_fir_mc_debug_plan(0, 1, 0, 10, 8, 1, 0, 0, None, 0) == 0
     assert fir.lib().if_fir_mc_debug_plan(2, 1, 2, 10, 8, 1, 0, 0, None, 0) == 0
     assert fir.lib().if_fir_mc_debug_plan(2, 1, 0, 10, 5, 1, 0, 0, None, 0) == 0
+
+
+def test_stand_in_transport_builds():
+    """tests/c/fake_rccl.cpp (the in-process transport the GPU tests load through IF_FIR_RCCL_LIBRARY) cross-compiles for
+    gfx950 and exports the eight entry points if_fir_mc.cpp resolves."""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(tempfile.mkdtemp(prefix="fake_rccl_"), "libfake_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17", "-x", "hip",
+                           os.path.join(root, "tests", "c", "fake_rccl.cpp"), "-o", so])
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclSend", "ncclRecv",
+                 "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+        assert (" T " + name) in syms, name
