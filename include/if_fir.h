@@ -98,13 +98,11 @@ uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat);
  * set since the last reset (the phase is a function of the absolute index).  Overlap-save and generic kernels only. */
 uint8_t if_fir_set_nco(if_fir_ctx_t *pCtx, double dFreq);
 uint8_t if_fir_get_nco(const if_fir_ctx_t *pCtx, double *pdFreq);
-/* expert knob: pick a tuning variant of the resolved backend's kernel (0 = default).  Variants change
- * speed only (1..9: schedules of the direct kernels, 2000 + k: at most k workgroups for the overlap-save kernel).
- * Development switches are closed unless the process runs with IF_FIR_DEBUG=1: 1000..1999 (diagnostic launches that skip
- * loads or stores: WRONG results), 4000 (the next call fails: test hook), and the IF_FIR_VARIANT environment variable
- * read at if_fir_init.
+/* expert knob: pick a schedule variant of the direct-form kernels (0 = default, 1..9).  Variants change
+ * speed only.  Everything else (diagnostic launches, grid limits, test hooks) lives in the development library, see
+ * if_fir_debug.h.
  * Environment: IF_FIR_RCCL_LIBRARY = path of the library providing the nccl* entry points of the multi-channel front
- * (default: librccl.so.1 by name). */
+ * (default: librccl.so.1 by name); IF_FIR_MC_TIMEOUT_S = seconds a rank waits for its peers' transfers (default 300). */
 uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant);
 /* (calls on a stream that is being captured into a hipGraph are refused: the streaming state advances on the host) */
 /* run on a caller-owned HIP stream (pass a hipStream_t as void*; NULL = the context's own stream) */
@@ -120,7 +118,8 @@ uint64_t if_fir_out_count(const if_fir_ctx_t *pCtx, uint64_t ullSamples);
 /* Host pointers: H2D copy + kernel + D2H copy, synchronous.  ullSamples ≤ ullMaxSamples of init. */
 uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float *pfIQOut, uint64_t ullSamples,
                        uint64_t *pullOutSamples);
-/* Device pointers (16-byte aligned), asynchronous on the context's stream; what the benchmark times.
+/* Device pointers, 16-byte aligned (the overlap-save backend, AUTO's pick, also takes pointers aligned to one sample:
+ * 8 bytes, 4 for int16 input), asynchronous on the context's stream; what the benchmark times.
  * pDevOut must hold if_fir_out_count() samples. */
 uint8_t if_fir_process_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
                               uint64_t *pullOutSamples);
@@ -129,10 +128,6 @@ uint8_t if_fir_process_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDev
 /* Fill pDevIQ with the SPEC §5 synthetic stream of channel ulChannel, samples [ullFirst, ullFirst+ullSamples). */
 uint8_t if_fir_synth_device(if_fir_ctx_t *pCtx, void *pDevIQ, uint64_t ullFirst, uint64_t ullSamples,
                             uint32_t ulChannel);
-/* Time ulReps back-to-back if_fir_process_device() calls with HIP events on the context's stream, after
- * ulWarmup untimed ones; *pfMsPerCall receives the mean.  History/phase are restored afterwards. */
-uint8_t if_fir_time_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
-                           uint32_t ulWarmup, uint32_t ulReps, float *pfMsPerCall);
 /* Device memory helpers so that a pure-C host needs no HIP headers. */
 /* mean(|y|^2) of a device IQ buffer (float32 I,Q), accumulated in float64; synchronous.  The measurement side of a
  * level-control loop; writing the attenuator register stays with the rack controller's daemon. */
@@ -145,17 +140,6 @@ uint8_t if_fir_dev_alloc(if_fir_ctx_t *pCtx, void **ppDev, uint64_t ullBytes);
 uint8_t if_fir_dev_free(if_fir_ctx_t *pCtx, void *pDev);
 uint8_t if_fir_dev_upload(if_fir_ctx_t *pCtx, void *pDev, const void *pHost, uint64_t ullBytes);
 uint8_t if_fir_dev_download(if_fir_ctx_t *pCtx, void *pHost, const void *pDev, uint64_t ullBytes);
-/* Diagnostics (development aid): first call with pullOut = NULL arms per-wave start/end time stamps for the
- * persistent direct-form kernel; later calls copy the last launch's stamps (4 x uint64 per wave) and return the
- * number of words written. */
-uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulWords);
-/* host-only diagnostic: the overlap-save kernel's table image (float32, ulOutFloats >= 21120) for these taps; returns the
- * number of floats written, 0 if the (taps, decimation) pair is not served by that kernel.  Used by the CPU tests. */
-uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
-                                 uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats);
-/* host-only diagnostic: block-queue layout of an overlap-save launch: pllOut[6] = blocks per group, groups, static groups
- * per workgroup, 0, upper bound of the global ticket counter, workgroups */
-uint8_t if_fir_debug_fft_schedule(uint64_t ullBlocks, uint32_t ulWorkgroups, int64_t *pllOut);
 /* "gfx950", CU count, etc.: writes a short description of the context's device */
 uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOutBytes);
 
@@ -185,8 +169,8 @@ typedef struct if_fir_mc_ctx if_fir_mc_ctx_t;
 
 uint32_t if_fir_mc_owner(uint32_t ulChannel, uint32_t ulWorld);
 uint8_t if_fir_mc_unique_id(uint8_t *pubId /* IF_FIR_MC_ID_BYTES */);
-/* pfTaps: ulChannels rows of ulTaps real float32 taps.  ullMaxSamples > 0: per-call limit (sizes the staging buffers
- * of the ranks other than 0).  pubId may be NULL when ulWorld == 1. */
+/* pfTaps: ulChannels rows of ulTaps real float32 taps.  ullMaxSamples > 0: per-call limit.  Ranks other than 0 stage two
+ * chunks per owned channel (not the whole call).  pubId may be NULL when ulWorld == 1. */
 uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, const float *pfTaps, uint32_t ulTaps,
                        uint32_t ulDecimation, uint64_t ullMaxSamples, int32_t lDevice, uint32_t ulRank,
                        uint32_t ulWorld, const uint8_t *pubId);
@@ -199,18 +183,18 @@ uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ulFormat);
  * A failing filter on any rank makes the call fail on that rank AND on rank 0 (the other ranks complete normally; the
  * transfer protocol is always run to its end, nobody is left waiting); the channel streams are then out of step:
  * call if_fir_mc_reset() on every rank before the next call.  After an RCCL failure the communicator is aborted and the
- * context refuses further calls (destroy it and create a new one). */
+ * context refuses further calls (destroy it and create a new one); the peers notice through the communicator's
+ * asynchronous error state, which their waits poll, or at the latest after IF_FIR_MC_TIMEOUT_S seconds (best effort:
+ * this path has run against a stand-in transport only, no multi-GPU node was available to the build). */
 uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDevIn, void *const *ppDevOut,
                                  uint64_t ullSamples, uint64_t *pullOutSamples);
 /* chunk length of the following calls: 0 = default (16 773 120 samples), UINT64_MAX = never split, otherwise a multiple of
- * 215 040 samples (the overlap-save blocks of a chunked call then start where those of an unchunked call start: results
- * are bit-identical whatever the chunk).  Every rank must make the same call. */
+ * 215 040 samples (the lcm of the overlap-save block advances).  The library rounds it up to a multiple of twice the
+ * decimation and, where the kernel's block grid follows the decimation phase (decimation 4), makes the first chunk of an
+ * off-phase call that many samples longer: the blocks of a chunked call are then the blocks of an unchunked one and the
+ * results are bit-identical whatever the chunk and whatever the phase (channels on the overlap-save backend, AUTO's
+ * pick).  Every rank must make the same call. */
 uint8_t if_fir_mc_set_chunk_samples(if_fir_mc_ctx_t *pCtx, uint64_t ullChunk);
-/* host-only diagnostic: the transfer plan of one rank for one call, 8 uint64 per operation {kind 0 send / 1 recv, phase
- * 0 scatter / 1 gather / 2 status, group, peer, channel, chunk, byte offset, bytes}; returns the operation count */
-uint32_t if_fir_mc_debug_plan(uint32_t ulWorld, uint32_t ulChannels, uint32_t ulRank, uint64_t ullSamples,
-                              uint32_t ulInBytes, uint32_t ulDecimation, uint64_t ullConsumed, uint64_t ullChunk,
-                              uint64_t *pullOut, uint32_t ulMaxOps);
 /* the single-channel context behind a channel this rank owns (NULL otherwise), e.g. for if_fir_set_backend() */
 if_fir_ctx_t *if_fir_mc_channel_ctx(if_fir_mc_ctx_t *pCtx, uint32_t ulChannel);
 const char *if_fir_mc_last_error(const if_fir_mc_ctx_t *pCtx);

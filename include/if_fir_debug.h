@@ -1,0 +1,51 @@
+/*
+ * if_fir_debug.h — development hooks of the IF-chain FIR library.  NOT part of the product ABI: these entry points and
+ * the tuning variants listed below exist only in libif_fir_dev.so (the same sources built with -DIF_FIR_DEVELOPMENT),
+ * which the test-suite and the tools under tools/ load; libif_fir.so exports none of them (tests/test_host.py checks).
+ *
+ * Development tuning variants of if_fir_set_tuning() (dev library only; the diagnostic ones additionally need
+ * IF_FIR_DEBUG=1 in the environment because their results are WRONG by construction):
+ *   2000 + k       at most k workgroups for the overlap-save kernel: same results; lets small inputs run through every
+ *                  stage of the block queue (tests/test_gpu_parity.py)
+ *   1000 + bits    diagnostic launches of the overlap-save kernel (IF_FIR_DEBUG=1): 1 skip the global loads, 2 skip the
+ *                  stores, 16 every wave fetches the same block, 32 static block map, 64 one wave per SIMD
+ *   1000000 + bits the same with room for more bits (round 3): 4 + (n << 12) late start of the second wave per SIMD,
+ *                  8 / 128 cache-line touches ahead of the next block group, ...  
+ *   4000           the next call fails before anything is launched (IF_FIR_DEBUG=1): lets tests reach callers' error paths
+ * Environment (dev library only): IF_FIR_DEBUG=1 IF_FIR_VARIANT=n preselects a variant at if_fir_init.
+ */
+#ifndef IF_FIR_DEBUG_H
+#define IF_FIR_DEBUG_H
+
+#include "if_fir.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Time ulReps back-to-back if_fir_process_device() calls with HIP events on the context's stream, after
+ * ulWarmup untimed ones; *pfMsPerCall receives the mean.  History/phase are restored afterwards. */
+uint8_t if_fir_time_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
+                           uint32_t ulWarmup, uint32_t ulReps, float *pfMsPerCall);
+/* first call with pullOut = NULL arms per-wave start/end time stamps for the persistent kernels; later calls copy the
+ * last launch's stamps (4 x uint64 per wave) and return the number of words written. */
+uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulWords);
+/* host-only: the overlap-save kernel's table image (float32, ulOutFloats >= IF_FIR_DEBUG_TABLE_FLOATS) for these taps;
+ * returns the number of floats written, 0 if the (taps, decimation) pair is not served by that kernel. */
+#define IF_FIR_DEBUG_TABLE_FLOATS 21120u
+uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
+                                 uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats);
+/* host-only: block-queue layout of an overlap-save launch: pllOut[6] = blocks per group, groups, static groups per
+ * workgroup, 0, upper bound of the global ticket counter, workgroups */
+uint8_t if_fir_debug_fft_schedule(uint64_t ullBlocks, uint32_t ulWorkgroups, int64_t *pllOut);
+/* host-only: the transfer plan of one rank of the multi-channel front for one call, 8 uint64 per operation {kind 0 send /
+ * 1 recv, phase 0 scatter / 1 gather / 2 status, group, peer, channel, chunk, byte offset in rank 0's channel buffer,
+ * bytes}; returns the operation count */
+uint32_t if_fir_mc_debug_plan(uint32_t ulWorld, uint32_t ulChannels, uint32_t ulRank, uint64_t ullSamples,
+                              uint32_t ulInBytes, uint32_t ulTaps, uint32_t ulDecimation, uint64_t ullConsumed,
+                              uint64_t ullChunk, uint64_t *pullOut, uint32_t ulMaxOps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IF_FIR_DEBUG_H */

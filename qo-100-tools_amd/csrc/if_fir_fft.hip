@@ -251,6 +251,10 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 #ifndef IF_FIR_FFT_EARLY_GROUPS
 #define IF_FIR_FFT_EARLY_GROUPS 3
 #endif
+// the first block's rows are requested ahead of the table copy (head of the launch)
+#ifndef IF_FIR_FFT_LOADS_FIRST
+#define IF_FIR_FFT_LOADS_FIRST 1
+#endif
 template <int AUX = 0>
 __device__ __forceinline__ cf buf_load(srd_t rsrc, unsigned voff, unsigned soff)
 {
@@ -271,10 +275,15 @@ __device__ __forceinline__ cf cvt_i16(unsigned w)
 template <bool I16, int AUX>
 __device__ __forceinline__ void load_row_aux(cf (&r)[64], srd_t rsrc, int lane, int row)
 {
+#ifdef IF_FIR_DIAG_CONTIG // (timing study builds only, results wrong: the 16 rows of a load batch are contiguous in memory)
+    const int mrow = 16 * ((row >> 2) & 3) + 4 * (row >> 4) + (row & 3);
+#else
+    const int mrow = row;
+#endif
     if constexpr (I16)
-        r[row].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)lane * 4u, row * 256, AUX));
+        r[row].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)lane * 4u, mrow * 256, AUX));
     else
-        r[row] = buf_load<AUX>(rsrc, (unsigned)lane * 8u, row * 512);
+        r[row] = buf_load<AUX>(rsrc, (unsigned)lane * 8u, mrow * 512);
 }
 // EDGE rows: the first and last `EDGE` rows of a block are the rows the neighbouring block shares with it; loaded with
 // the default policy they are served to the neighbour from L2 (IF_FIR_FFT_EDGE_CACHED=0 switches that off for A/B runs)
@@ -315,7 +324,30 @@ __host__ __device__ __forceinline__ constexpr int64_t fft_static_group(int local
 {
     return (int64_t)local_group * wgs + wg;
 }
-__device__ __forceinline__ int64_t queue_take(char *smem, unsigned int *gqueue, int lane)
+// (development, diag 8 / 128) touch one dword of every 128-byte line of [base + first, base + first + n8k * 8 KiB): the lines
+// land in L2 / the memory-side cache ahead of the row loads.  The destination is v255, which the kernel never allocates
+// (it uses ~212 VGPRs; the clobber raises the count to 256 = still two waves per SIMD), so the loads are fire-and-forget.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void prefetch_span(const char *base, int64_t first, int64_t limit, int n8k, int lane)
+{
+    if (first < 0 || first >= limit)
+        return;
+    const uint64_t a = (uint64_t)(base + first);
+    const int64_t room = limit - first;
+    u32x4_t srd;
+    srd.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    srd.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    srd.z = __builtin_amdgcn_readfirstlane((unsigned)(room > 0x7fffffffLL ? 0x7fffffffLL : room));
+    srd.w = 0x00020000u;
+    const unsigned voff = (unsigned)lane * 128u;
+    for (int k = 0; k < n8k; k++)
+    {
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)k * 8192u);
+        asm volatile("buffer_load_dword v255, %0, %1, %2 offen" ::"v"(voff), "s"(srd), "s"(soff) : "v255");
+    }
+}
+
+__device__ __forceinline__ int64_t queue_take(char *smem, unsigned int *gqueue, int lane, unsigned *local_group = nullptr)
 {
     unsigned int *cnt = reinterpret_cast<unsigned int *>(smem + LDS_Q);
     unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16);
@@ -345,7 +377,17 @@ __device__ __forceinline__ int64_t queue_take(char *smem, unsigned int *gqueue, 
         __builtin_amdgcn_s_sleep(2);
     }
     const unsigned gg = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
+    if (local_group)
+        *local_group = g;
     return (int64_t)gg * 8 + j;
+}
+// global group of local group g if its ring entry has been published already, else -1 (never waits)
+__device__ __forceinline__ int64_t queue_peek(char *smem, unsigned g)
+{
+    const unsigned long long *ring = reinterpret_cast<const unsigned long long *>(smem + LDS_Q + 16);
+    const unsigned long long e = __hip_atomic_load(&ring[g & (Q_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)e), hi = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
+    return lo == g ? (int64_t)hi : -1;
 }
 
 // decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
@@ -418,6 +460,31 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cf r[64];
+    bool loaded = false; // the rows of `blk` are already in flight (issued by the prologue or the previous iteration's epilogue)
+    // ---- first block: static (wave w of workgroup b takes block w of global group b), and its rows are requested BEFORE
+    //      the table copy below, so that the two transfers overlap at the head of the launch
+    const bool plain_start = IF_FIR_FFT_LOADS_FIRST && !(diag & (32 | 64));
+    int64_t blk = 0;
+    if (plain_start)
+    {
+        blk = fft_static_group(0, blockIdx.x, gridDim.x) * FFT_WAVES + wid;
+        // diag 4 (development, results stay correct): the second wave of every SIMD starts (diag >> 12) & 255 sleeps later
+        if ((diag & 4) && wid >= FFT_WAVES / 2)
+            for (int k = 0; k < ((diag >> 12) & 255); k++)
+                __builtin_amdgcn_s_sleep(32);
+        const int64_t s0 = blk * L - OVL + n0 - in_shift;
+        if (blk < nblocks && s0 >= 0 && !(diag & 1))
+        {
+            const srd_t srd = make_srd(in + s0 * ISZ, (N - s0) * ISZ);
+#pragma unroll
+            for (int rho = 0; rho < 4; rho++)
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    load_row<I16, LAUX, OVL_ROWS>(r, srd, lane, 4 * j + rho);
+            loaded = true;
+        }
+    }
     // ---- tables: global -> LDS (once per workgroup) ------------------------------------------------------------
     {
         const f4v_t *src = reinterpret_cast<const f4v_t *>(tables);
@@ -434,7 +501,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         }
         if (threadIdx.x == 0)
         {
-            *reinterpret_cast<unsigned int *>(smem + LDS_Q) = 0u;
+            // (the first FFT_WAVES slots = local group 0 were taken statically above)
+            *reinterpret_cast<unsigned int *>(smem + LDS_Q) = plain_start ? (unsigned)FFT_WAVES : 0u;
             // the other global counter is the next launch's: zero it here (this launch never touches it)
             if (blockIdx.x == 0)
                 queue[qsel ^ 1u] = 0u;
@@ -500,7 +568,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     const int32_t waves_total = (int32_t)gridDim.x * FFT_WAVES;
     // diag 64 (development, results stay correct): waves 4-7 of every workgroup leave at once = one wave per SIMD
     // (occupancy experiment; the queue hands their share to the others)
-    int64_t blk = (diag & 32) ? 0 : ((diag & 64) && wid >= FFT_WAVES / 2) ? nblocks : queue_take(smem, gqueue, lane);
+    if (!plain_start)
+        blk = (diag & 32) ? 0 : ((diag & 64) && wid >= FFT_WAVES / 2) ? nblocks : queue_take(smem, gqueue, lane);
     // diag 32 (development, results stay correct): static wave-interleaved blocks, no queue: block = it * waves + wave
     const bool static_map = (diag & 32) != 0;
     const int act_waves = (diag & 64) ? FFT_WAVES / 2 : FFT_WAVES;
@@ -509,8 +578,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     {
         blk = (wid < act_waves) ? (int64_t)blockIdx.x * act_waves + wid : nblocks;
     }
-    cf r[64];
-    bool loaded = false; // the rows of `blk` are already in flight (issued by the previous iteration's epilogue)
     const unsigned voff = (unsigned)lane * 8u;
     while (blk < nblocks)
     {
@@ -617,7 +684,25 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         {
             // taken here: the block's own rows have all landed and the next block's are not issued yet, so the wait
             // behind the (rare) global atomic inside drains nothing
-            blk_next = queue_take(smem, gqueue, lane);
+            unsigned lg = 0;
+            blk_next = queue_take(smem, gqueue, lane, &lg);
+            // diag 8 / 128 (development, results stay correct): the lines of the NEXT local group are touched ahead of time,
+            // 8: all 8 blocks by the wave that took slot 0 (one CU requests its 240 KB together), 128: block j by the taker of slot j
+            if (diag & (8 | 128))
+            {
+                const unsigned jn = (unsigned)blk_next & 7u;
+                if ((diag & 128) || jn == 0)
+                {
+                    const int64_t gg1 = queue_peek(smem, lg + 1);
+                    const int64_t b0 = gg1 * 8 + ((diag & 128) ? (int64_t)jn : 0);
+                    if (gg1 >= 0 && b0 < nblocks)
+                    {
+                        const int64_t f0 = b0 * L - OVL + n0 - in_shift;
+                        const int64_t nb = (int64_t)((diag & 128) ? FFT_N : 8 * L + OVL) * ISZ;
+                        prefetch_span(in, f0 * ISZ, N * ISZ, (int)((nb + 8191) / 8192), lane);
+                    }
+                }
+            }
         }
         const int64_t s0n = blk_next * L - OVL + n0 - in_shift;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);

@@ -15,12 +15,17 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 
 #include "if_fir.h"
+#ifdef IF_FIR_DEVELOPMENT
+#include "if_fir_debug.h"
+#endif
 
 #define IF_FIR_API extern "C" __attribute__((visibility("default")))
 
@@ -33,6 +38,7 @@ struct RcclApi
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -83,6 +89,7 @@ RcclApi *rccl()
     IF_FIR_SYM(GetErrorString, "ncclGetErrorString");
 #undef IF_FIR_SYM
     g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(lib, "ncclCommAbort"));
+    g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(lib, "ncclCommGetAsyncError"));
     g_rccl.lib = lib;
     return &g_rccl;
 }
@@ -107,11 +114,17 @@ struct if_fir_mc_ctx
     uint32_t *d_status = nullptr;      // device: [0] this rank's status word, [1 + r] = rank r's as received by the root
     bool comm_broken = false;
     std::vector<if_fir_ctx_t *> fir; // per channel; nullptr for channels other ranks own
-    std::vector<void *> stage_in, stage_out; // owned channels of non-root ranks
+    // owned channels of ranks other than 0: TWO slots each (chunk k lives in slot k & 1; the transfer plan's order makes the
+    // reuse safe, see if_fir_mc_process_device), sized by the chunk, not by the longest call
+    std::vector<void *> stage_in, stage_out;
+    uint64_t slot_samples = 0;                  // input samples one slot holds
+    size_t slot_in_bytes = 0, slot_out_bytes = 0;
     RcclApi *api = nullptr;
     ncclComm_t comm = nullptr;
     mutable char err[256] = "";
 };
+
+static uint64_t mc_slot_samples(uint64_t samples, uint64_t chunk, uint32_t decim);
 
 static void mc_err(const if_fir_mc_ctx *ctx, const char *fmt, ...)
 {
@@ -202,6 +215,45 @@ static void mc_free(if_fir_mc_ctx *ctx)
     delete ctx;
 }
 
+// staging of the ranks other than 0: two slots of `need` input samples (and their outputs) per owned channel; grows on
+// demand (a longer chunk setting), never shrinks
+static uint8_t mc_ensure_staging(if_fir_mc_ctx *ctx, uint64_t need)
+{
+    if (ctx->rank == 0 || need <= ctx->slot_samples)
+        return 1;
+    if (hipSetDevice(ctx->device) != hipSuccess)
+        return 0;
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->xfer_stream)
+        (void)hipStreamSynchronize(ctx->xfer_stream);
+    const size_t in_b = ((size_t)need * 8 + 255) & ~(size_t)255;
+    const size_t out_b = ((size_t)(need / ctx->decim + 2) * 8 + 255) & ~(size_t)255;
+    for (uint32_t c = 0; c < ctx->channels; c++)
+    {
+        if (!ctx->fir[c])
+            continue;
+        if (ctx->stage_in[c])
+            (void)hipFree(ctx->stage_in[c]);
+        if (ctx->stage_out[c])
+            (void)hipFree(ctx->stage_out[c]);
+        ctx->stage_in[c] = ctx->stage_out[c] = nullptr;
+        ctx->slot_samples = 0;
+        hipError_t e = hipMalloc(&ctx->stage_in[c], 2 * in_b);
+        if (e == hipSuccess)
+            e = hipMalloc(&ctx->stage_out[c], 2 * out_b);
+        if (e != hipSuccess)
+        {
+            mc_err(ctx, "staging for channel %u (2 x %llu samples): %s", c, (unsigned long long)need, hipGetErrorString(e));
+            return 0;
+        }
+    }
+    ctx->slot_samples = need;
+    ctx->slot_in_bytes = in_b;
+    ctx->slot_out_bytes = out_b;
+    return 1;
+}
+
 IF_FIR_API uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, const float *pfTaps, uint32_t ulTaps,
                                   uint32_t ulDecimation, uint64_t ullMaxSamples, int32_t lDevice, uint32_t ulRank,
                                   uint32_t ulWorld, const uint8_t *pubId)
@@ -263,15 +315,12 @@ IF_FIR_API uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, 
             MC_INIT_FAIL("if_fir_mc_init: channel %u: %s", c, if_fir_last_error(nullptr));
         if (!if_fir_set_stream(ctx->fir[c], ctx->stream))
             MC_INIT_FAIL("if_fir_mc_init: channel %u: %s", c, if_fir_last_error(ctx->fir[c]));
-        if (ulRank != 0)
-        {
-            const size_t out_max = (size_t)((ullMaxSamples + ulDecimation - 1) / ulDecimation + 1) * 8;
-            e = hipMalloc(&ctx->stage_in[c], (size_t)ullMaxSamples * 8);
-            if (e == hipSuccess)
-                e = hipMalloc(&ctx->stage_out[c], out_max);
-            if (e != hipSuccess)
-                MC_INIT_FAIL("if_fir_mc_init: staging for channel %u: %s", c, hipGetErrorString(e));
-        }
+    }
+    if (!mc_ensure_staging(ctx, mc_slot_samples(ullMaxSamples, ctx->chunk_samples, ulDecimation)))
+    {
+        snprintf(g_mc_init_err, sizeof(g_mc_init_err), "if_fir_mc_init: %s", ctx->err);
+        mc_free(ctx);
+        return 0;
     }
     if (ulWorld > 1)
     {
@@ -376,18 +425,61 @@ static uint64_t mc_out_count(uint64_t consumed, uint64_t n, uint32_t d)
     return n > n0 ? (n - n0 + d - 1) / d : 0;
 }
 
-static void mc_chunks(uint64_t samples, uint64_t chunk, uint64_t consumed, uint32_t decim, std::vector<McChunk> &out)
+static uint64_t mc_gcd(uint64_t a, uint64_t b)
+{
+    while (b)
+    {
+        const uint64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+// The decimate-by-4 overlap-save kernel (<= 3073 taps) anchors its block grid at the call's first OUTPUT (n0 samples
+// into the call when the stream position is off-phase); every other kernel anchors it at the call's first sample.
+static bool mc_grid_follows_phase(uint32_t taps, uint32_t decim)
+{
+    return decim == 4 && taps <= 3073;
+}
+
+// Chunk table of a call.  The effective chunk is the least common multiple of the requested chunk (a multiple of
+// MC_CHUNK_UNIT, the lcm of the block advances) and 2 D: every chunk then produces an even number of outputs whatever the
+// phase, so the output pieces start at even sample offsets.  Where the kernel's block grid follows the decimation phase
+// the FIRST chunk is n0 samples longer: the chunks behind it then start on phase 0 AND on the block grid of the unsplit
+// call, and no block of a chunk reaches past the chunk's end -- chunked results equal unchunked ones bit for bit at any
+// phase (the input pieces may then start at odd sample offsets, which the overlap-save kernel accepts).
+static void mc_chunks(uint64_t samples, uint64_t chunk, uint64_t consumed, uint32_t decim, uint32_t taps,
+                      std::vector<McChunk> &out)
 {
     out.clear();
+    if (chunk)
+    {
+        const uint64_t two_d = 2ull * decim;
+        chunk = chunk / mc_gcd(chunk, two_d) * two_d;
+    }
+    const uint64_t n0 = (decim - consumed % decim) % decim;
+    const uint64_t shift = mc_grid_follows_phase(taps, decim) ? n0 : 0;
     uint64_t done = 0, outs = 0;
     while (done < samples)
     {
-        const uint64_t n = (chunk && samples - done > chunk) ? chunk : samples - done;
+        const uint64_t want = chunk ? chunk + (done == 0 ? shift : 0) : 0;
+        const uint64_t n = (want && samples - done > want) ? want : samples - done;
         const uint64_t m = mc_out_count(consumed + done, n, decim);
         out.push_back({done, n, outs, m});
         done += n;
         outs += m;
     }
+}
+
+// capacity (samples) of one staging slot of a rank other than 0: the longest chunk a call of `samples` can have
+static uint64_t mc_slot_samples(uint64_t samples, uint64_t chunk, uint32_t decim)
+{
+    if (!chunk)
+        return samples;
+    const uint64_t two_d = 2ull * decim;
+    const uint64_t eff = chunk / mc_gcd(chunk, two_d) * two_d + decim;
+    return eff < samples ? eff : samples;
 }
 
 // every transfer operation of `rank` for one call, in the order it posts them
@@ -441,16 +533,17 @@ static void mc_plan(uint32_t world, uint32_t channels, uint32_t rank, const std:
     }
 }
 
+#ifdef IF_FIR_DEVELOPMENT
 // Host-only: the transfer plan of one rank as 8 uint64 per operation {kind, phase, group, peer, channel, chunk, offset,
 // bytes}; returns the number of operations (also when pullOut is too small or NULL).  ullChunk = 0: one piece.
 IF_FIR_API uint32_t if_fir_mc_debug_plan(uint32_t ulWorld, uint32_t ulChannels, uint32_t ulRank, uint64_t ullSamples,
-                                         uint32_t ulInBytes, uint32_t ulDecimation, uint64_t ullConsumed, uint64_t ullChunk,
-                                         uint64_t *pullOut, uint32_t ulMaxOps)
+                                         uint32_t ulInBytes, uint32_t ulTaps, uint32_t ulDecimation, uint64_t ullConsumed,
+                                         uint64_t ullChunk, uint64_t *pullOut, uint32_t ulMaxOps)
 {
-    if (!ulWorld || !ulChannels || ulRank >= ulWorld || !ulDecimation || (ulInBytes != 4 && ulInBytes != 8))
+    if (!ulWorld || !ulChannels || ulRank >= ulWorld || !ulDecimation || !ulTaps || (ulInBytes != 4 && ulInBytes != 8))
         return 0;
     std::vector<McChunk> chunks;
-    mc_chunks(ullSamples, ullChunk, ullConsumed, ulDecimation, chunks);
+    mc_chunks(ullSamples, ullChunk, ullConsumed, ulDecimation, ulTaps, chunks);
     std::vector<McXfer> ops;
     mc_plan(ulWorld, ulChannels, ulRank, chunks, ulInBytes, ops);
     for (size_t i = 0; pullOut && i < ops.size() && i < ulMaxOps; i++)
@@ -461,6 +554,8 @@ IF_FIR_API uint32_t if_fir_mc_debug_plan(uint32_t ulWorld, uint32_t ulChannels, 
     }
     return (uint32_t)ops.size();
 }
+
+#endif // IF_FIR_DEVELOPMENT
 
 // chunk length of the calls that follow: 0 = default (~2^24 samples), otherwise a multiple of 215040 samples (see above);
 // UINT64_MAX = never split.  Every rank must make the same call.
@@ -517,7 +612,19 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
             }
     MC_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<McChunk> chunks;
-    mc_chunks(ullSamples, ctx->chunk_samples, ctx->consumed, ctx->decim, chunks);
+    mc_chunks(ullSamples, ctx->chunk_samples, ctx->consumed, ctx->decim, ctx->taps, chunks);
+    {
+        uint64_t longest = 0;
+        for (const McChunk &ch : chunks)
+            longest = ch.in_count > longest ? ch.in_count : longest;
+        if (!mc_ensure_staging(ctx, longest))
+            return 0;
+    }
+    // ranks other than 0 keep chunk k of an owned channel in slot k & 1 of its staging buffers.  Reuse is ordered by the
+    // plan itself: on the transfer stream S(k+2) comes behind G(k), which waits for filter k (ev_out[k]); filter k+2 waits
+    // for S(k+2) (ev_in[k+2]), i.e. for G(k) to have sent slot k & 1 of the outputs.
+    auto stage_in_at = [&](uint32_t c, uint32_t k) { return (char *)ctx->stage_in[c] + (size_t)(k & 1u) * ctx->slot_in_bytes; };
+    auto stage_out_at = [&](uint32_t c, uint32_t k) { return (char *)ctx->stage_out[c] + (size_t)(k & 1u) * ctx->slot_out_bytes; };
     std::vector<McXfer> ops;
     mc_plan(ctx->world, ctx->channels, ctx->rank, chunks, ctx->in_bytes, ops);
     const uint32_t nchunks = (uint32_t)chunks.size();
@@ -544,16 +651,17 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
             const McXfer &o = ops[next_op];
             if (!opened || rccl_fail)
                 continue;
+            // (the plan's byte offsets are positions in rank 0's channel buffers; the other ranks use their chunk slots)
             char *buf;
             if (o.phase == MC_PHASE_STATUS)
-                buf = reinterpret_cast<char *>(ctx->d_status);
+                buf = reinterpret_cast<char *>(ctx->d_status) + o.offset;
             else if (o.phase == MC_PHASE_SCATTER)
-                buf = root ? (char *)const_cast<void *>(ppDevIn[o.channel]) : (char *)ctx->stage_in[o.channel];
+                buf = root ? (char *)const_cast<void *>(ppDevIn[o.channel]) + o.offset : stage_in_at(o.channel, o.chunk);
             else
-                buf = root ? (char *)ppDevOut[o.channel] : (char *)ctx->stage_out[o.channel];
+                buf = root ? (char *)ppDevOut[o.channel] + o.offset : stage_out_at(o.channel, o.chunk);
             const ncclResult_t r = o.kind == MC_SEND
-                                       ? ctx->api->Send(buf + o.offset, o.bytes, ncclUint8, (int)o.peer, ctx->comm, ctx->xfer_stream)
-                                       : ctx->api->Recv(buf + o.offset, o.bytes, ncclUint8, (int)o.peer, ctx->comm, ctx->xfer_stream);
+                                       ? ctx->api->Send(buf, o.bytes, ncclUint8, (int)o.peer, ctx->comm, ctx->xfer_stream)
+                                       : ctx->api->Recv(buf, o.bytes, ncclUint8, (int)o.peer, ctx->comm, ctx->xfer_stream);
             if (r != ncclSuccess && first_bad == ncclSuccess)
                 first_bad = r;
         }
@@ -576,8 +684,8 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
             if (!ctx->fir[c])
                 continue;
             uint64_t m = 0;
-            const char *src = (root ? (const char *)ppDevIn[c] : (const char *)ctx->stage_in[c]) + ch.in_first * ctx->in_bytes;
-            char *dst = (root ? (char *)ppDevOut[c] : (char *)ctx->stage_out[c]) + ch.out_first * 8;
+            const char *src = root ? (const char *)ppDevIn[c] + ch.in_first * ctx->in_bytes : stage_in_at(c, k);
+            char *dst = root ? (char *)ppDevOut[c] + ch.out_first * 8 : stage_out_at(c, k);
             if (!if_fir_process_device(ctx->fir[c], src, dst, ch.in_count, &m))
             {
                 mc_err(ctx, "channel %u: %s", c, if_fir_last_error(ctx->fir[c]));
@@ -648,27 +756,67 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
         }
     }
 #undef MC_STEP
-    hipError_t se = hipStreamSynchronize(ctx->stream);
+    // Wait for both streams.  With ranks on other GPUs a failure THERE (a peer that aborted its communicator, a dead
+    // process) shows up here as a transfer that never completes: the wait polls the communicator's asynchronous error
+    // state and gives up after IF_FIR_MC_TIMEOUT_S seconds (default 300) instead of blocking for ever.
+    auto wait_stream = [&](hipStream_t st) -> hipError_t {
+        if (!moving || !ctx->api)
+            return hipStreamSynchronize(st);
+        const char *te = getenv("IF_FIR_MC_TIMEOUT_S");
+        const double limit = te && atof(te) > 0 ? atof(te) : 300.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++)
+        {
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipErrorNotReady)
+                return q;
+            if ((spins & 63u) == 63u)
+            {
+                ncclResult_t ar = ncclSuccess;
+                if (ctx->api->CommGetAsyncError && ctx->comm &&
+                    ctx->api->CommGetAsyncError(ctx->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+                {
+                    if (!rccl_fail)
+                        mc_err(ctx, "RCCL reported an asynchronous error while transfers were in flight: %s",
+                               ctx->api->GetErrorString(ar));
+                    rccl_fail = true;
+                    return hipSuccess;
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+                {
+                    if (!rccl_fail)
+                        mc_err(ctx, "transfers did not complete within %.0f s (a peer has failed or left): communicator aborted",
+                               limit);
+                    rccl_fail = true;
+                    return hipSuccess;
+                }
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    };
+    hipError_t se = wait_stream(ctx->stream);
     if (he == hipSuccess)
         he = se;
-    if (ctx->xfer_stream)
+    if (ctx->xfer_stream && !rccl_fail)
     {
-        se = hipStreamSynchronize(ctx->xfer_stream);
+        se = wait_stream(ctx->xfer_stream);
         if (he == hipSuccess)
             he = se;
     }
-    free_events();
     if (rccl_fail)
     {
-        // peers may be blocked in a transfer this rank never posted: abort the communicator so that they fail instead
+        // abort BEFORE anything waits on the streams again (destroying the events, freeing buffers): the aborted
+        // communicator's kernels leave the streams
         if (ctx->api && ctx->api->CommAbort && ctx->comm)
         {
             (void)ctx->api->CommAbort(ctx->comm);
             ctx->comm = nullptr;
         }
         ctx->comm_broken = true;
-        return 0;
     }
+    free_events();
+    if (rccl_fail)
+        return 0; // (peers see the aborted communicator through their own polling wait, or run into its time limit)
     if (he != hipSuccess)
     {
         mc_err(ctx, "if_fir_mc_process_device: %s", hipGetErrorString(he));

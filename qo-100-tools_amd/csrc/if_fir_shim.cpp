@@ -13,6 +13,9 @@
 #include <new>
 
 #include "if_fir.h"
+#ifdef IF_FIR_DEVELOPMENT
+#include "if_fir_debug.h"
+#endif
 #include "if_fir_kernels.h"
 
 #define IF_FIR_API extern "C" __attribute__((visibility("default")))
@@ -110,11 +113,13 @@ static int hist_len_for(int T)
     return ovl > need ? ovl : need;
 }
 
+#ifdef IF_FIR_DEVELOPMENT
 static bool debug_enabled()
 {
     const char *e = getenv("IF_FIR_DEBUG");
     return e && *e && *e != '0';
 }
+#endif
 
 static bool backend_ok(const if_fir_ctx *ctx, uint32_t b)
 {
@@ -285,9 +290,11 @@ static uint8_t init_common(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t u
         if_fir_destroy(ctx);
         return 0;
     }
-    // development only: IF_FIR_DEBUG=1 IF_FIR_VARIANT=n preselects a tuning variant (ignored in production)
+#ifdef IF_FIR_DEVELOPMENT
+    // development library only: IF_FIR_DEBUG=1 IF_FIR_VARIANT=n preselects a tuning variant
     const char *v = debug_enabled() ? getenv("IF_FIR_VARIANT") : nullptr;
     ctx->variant = v ? atoi(v) : 0;
+#endif
     ctx->err[0] = 0;
     *ppCtx = ctx;
     return 1;
@@ -393,14 +400,23 @@ IF_FIR_API uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant)
 {
     if (!pCtx)
         return 0;
-    // 1000..1999 are diagnostic launches of the overlap-save kernel that skip loads or stores (WRONG results, for
-    // timing studies): refused unless the process runs with IF_FIR_DEBUG=1.  Everything else changes speed only.
-    if (((ulVariant >= 1000 && ulVariant < 2000) || ulVariant == 4000) && !debug_enabled())
+#ifdef IF_FIR_DEVELOPMENT
+    // (if_fir_debug.h) diagnostic launches of the overlap-save kernel skip loads or stores (WRONG results, for timing
+    // studies) and 4000 injects a failure: refused unless the process runs with IF_FIR_DEBUG=1
+    if (((ulVariant >= 1000 && ulVariant < 2000) || ulVariant == 4000 || ulVariant >= 1000000) && !debug_enabled())
     {
         set_err(pCtx, "if_fir_set_tuning: variant %u is a diagnostic launch (wrong results); set IF_FIR_DEBUG=1 to allow it",
                 ulVariant);
         return 0;
     }
+#else
+    if (ulVariant > 9)
+    {
+        set_err(pCtx, "if_fir_set_tuning: variant %u is not a schedule variant (0..9); development variants exist in "
+                      "libif_fir_dev.so only (if_fir_debug.h)", ulVariant);
+        return 0;
+    }
+#endif
     pCtx->variant = (int)ulVariant;
     return 1;
 }
@@ -458,17 +474,24 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
         set_err(ctx, "if_fir_process_device: sample count too large");
         return 0;
     }
+#ifdef IF_FIR_DEVELOPMENT
     if (ctx->variant == 4000 && debug_enabled())
     {
-        // test hook (IF_FIR_DEBUG=1 only): the next call fails before anything is launched -- lets the tests exercise the
-        // error paths of callers (the multi-channel front's status word) without breaking a device
+        // test hook (dev library, IF_FIR_DEBUG=1): the next call fails before anything is launched -- lets the tests exercise
+        // the error paths of callers (the multi-channel front's status word) without breaking a device
         ctx->variant = 0;
         set_err(ctx, "if_fir_process_device: injected failure (tuning variant 4000, test hook)");
         return 0;
     }
-    if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+#endif
+    // the direct-form kernels move 16 bytes per lane; the overlap-save kernel moves one sample per lane and takes any
+    // sample-aligned pointer (the chunked multi-channel front hands it pieces that start at odd sample offsets)
+    const uintptr_t in_mask = ctx->backend == IF_FIR_BACKEND_HIP_FFT ? (ctx->in_i16 ? 3 : 7) : 15;
+    const uintptr_t out_mask = ctx->backend == IF_FIR_BACKEND_HIP_FFT ? 7 : 15;
+    if (((uintptr_t)in & in_mask) || ((uintptr_t)out & out_mask))
     {
-        set_err(ctx, "if_fir_process_device: device pointers must be 16-byte aligned");
+        set_err(ctx, "if_fir_process_device: device pointers must be %u-byte (input) and %u-byte (output) aligned for this "
+                     "backend", (unsigned)in_mask + 1, (unsigned)out_mask + 1);
         return 0;
     }
     uint32_t n0 = 0;
@@ -510,12 +533,14 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.fft_tables_b = (ctx->d_fft_tables && if_fir::fft_two_partitions(ctx->T))
                          ? static_cast<const float *>(ctx->d_fft_tables) + if_fir::FFT_TABLE_FLOATS : nullptr;
     a.queue = ctx->d_queue;
+#ifdef IF_FIR_DEVELOPMENT
     a.dbg = ctx->d_dbg;
-    // FFT tuning variants: 1000 + bits = development diagnostics (wrong results), 2000 + k = launch at most k workgroups
-    // (same results; lets small inputs go through the run queue, tests/test_gpu_parity.py)
+    // FFT tuning variants (if_fir_debug.h): 1000 + bits / 1000000 + bits = diagnostics, 2000 + k = at most k workgroups
     const bool fft_var = ctx->backend == IF_FIR_BACKEND_HIP_FFT;
-    a.diag = (fft_var && ctx->variant >= 1000 && ctx->variant < 2000) ? ctx->variant - 1000 : 0;
+    a.diag = (fft_var && ctx->variant >= 1000 && ctx->variant < 2000) ? ctx->variant - 1000
+             : (fft_var && ctx->variant >= 1000000 && ctx->variant < 3000000) ? ctx->variant - 1000000 : 0;
     a.grid_limit = (fft_var && ctx->variant > 2000 && ctx->variant < 3000) ? ctx->variant - 2000 : 0;
+#endif
     if (chan)
     {
         // mix-down phase of every channel at this call's first output: exp(-j 2 pi slot (consumed + n0) / 16)
@@ -730,6 +755,7 @@ IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float
     return 1;
 }
 
+#ifdef IF_FIR_DEVELOPMENT
 // Host-only: the overlap-save kernel's LDS table image (twiddles, H or the merged G table, NCO row phasors) for a set
 // of taps, as fft_build_tables() computes it in float64.  Needs no device: the CPU tests check it against numpy.
 IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps,
@@ -759,6 +785,8 @@ IF_FIR_API uint8_t if_fir_debug_fft_schedule(uint64_t ullBlocks, uint32_t ulWork
     pllOut[5] = s.wgs;
     return 1;
 }
+
+#endif // IF_FIR_DEVELOPMENT
 
 // Mean power of a device IQ buffer, mean(|y|^2): what a control loop feeds back into an attenuator (the
 // reference's rack controller sets the IF attenuation through I2C register 0x20, lib/upconverter.js:176-187; the
@@ -821,6 +849,7 @@ IF_FIR_API uint8_t if_fir_synth_device(if_fir_ctx_t *pCtx, void *pDevIQ, uint64_
     return 1;
 }
 
+#ifdef IF_FIR_DEVELOPMENT
 IF_FIR_API uint8_t if_fir_time_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut, uint64_t ullSamples,
                                       uint32_t ulWarmup, uint32_t ulReps, float *pfMsPerCall)
 {
@@ -860,6 +889,8 @@ IF_FIR_API uint8_t if_fir_time_device(if_fir_ctx_t *pCtx, const void *pDevIn, vo
     *pfMsPerCall = ms / (float)ulReps;
     return 1;
 }
+
+#endif // IF_FIR_DEVELOPMENT
 
 IF_FIR_API uint8_t if_fir_dev_alloc(if_fir_ctx_t *pCtx, void **ppDev, uint64_t ullBytes)
 {
@@ -908,6 +939,7 @@ IF_FIR_API uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, ui
     return 1;
 }
 
+#ifdef IF_FIR_DEVELOPMENT
 // Diagnostics: the first call (pullOut == NULL or ulWords == 0) arms per-wave start/end stamps for the persistent
 // direct kernel; later calls copy the stamps of the last launch (4 x uint64 per wave: realtime start/end in 10 ns
 // ticks, shader clock start/end) and return the number of uint64 words written.
@@ -936,6 +968,8 @@ IF_FIR_API uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, u
         return 0;
     return n;
 }
+
+#endif // IF_FIR_DEVELOPMENT
 
 // Input sample format: IF_FIR_INPUT_F32 (default) or IF_FIR_INPUT_I16 = interleaved int16 I,Q with
 // value = int16 * 2^-15, converted inside the kernels' loads (overlap-save and generic backends).  Must be chosen

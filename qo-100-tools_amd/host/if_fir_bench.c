@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include "if_fir.h"
 
@@ -52,10 +53,35 @@ static uint8_t bench_run(uint32_t ulTaps, uint32_t ulDecimation, uint32_t ulLog2
         goto done;
     }
 
-    if(!if_fir_time_device(pFir, pDevIn, pDevOut, ullSamples, 10, ulReps, &fMs))
+    /* product ABI only: back-to-back asynchronous calls between two synchronisations, host clock around them */
     {
-        fprintf(stderr, "if_fir_time_device: %s\n", if_fir_last_error(pFir));
-        goto done;
+        struct timespec t0, t1;
+        uint32_t i;
+
+        for(i = 0; i < 10; i++)
+            if(!if_fir_process_device(pFir, pDevIn, pDevOut, ullSamples, NULL))
+                break;
+
+        if(i < 10 || !if_fir_synchronize(pFir))
+        {
+            fprintf(stderr, "if_fir_process_device: %s\n", if_fir_last_error(pFir));
+            goto done;
+        }
+
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+
+        for(i = 0; i < ulReps; i++)
+            if(!if_fir_process_device(pFir, pDevIn, pDevOut, ullSamples, NULL))
+                break;
+
+        if(i < ulReps || !if_fir_synchronize(pFir))
+        {
+            fprintf(stderr, "if_fir_process_device: %s\n", if_fir_last_error(pFir));
+            goto done;
+        }
+
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        fMs = (float)(((double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6) / (double)ulReps);
     }
 
     if_fir_device_info(pFir, szInfo, sizeof(szInfo));

@@ -1,5 +1,10 @@
 """ctypes binding of libif_fir.so — one Python method per C entry point of include/if_fir.h (same names, same
-argument meaning, 1/0 status turned into IfFirError).  No compute happens here."""
+argument meaning, 1/0 status turned into IfFirError).  No compute happens here.
+
+Two libraries: libif_fir.so is the product (include/if_fir.h); libif_fir_dev.so is the same code with the development
+hooks of include/if_fir_debug.h compiled in (diagnostic tuning variants, stamps, the host-only table / schedule / plan
+dumps, if_fir_time_device).  `IfFir(..., dev=True)` / `IfFirMc(..., dev=True)` and the module-level debug_* helpers use
+the development library; everything else uses the product."""
 import ctypes
 import os
 
@@ -7,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libif_fir.so")
+DEV_LIB_PATH = os.path.join(_HERE, "libif_fir_dev.so")
 
 INPUT_F32, INPUT_I16 = 0, 1
 BACKEND_AUTO, BACKEND_HIP_DIRECT, BACKEND_HIP_TAPSPLIT, BACKEND_HIP_GENERIC, BACKEND_HIP_FFT = range(5)
@@ -16,14 +22,17 @@ WINDOW_RECT, WINDOW_HAMMING, WINDOW_HANN, WINDOW_BLACKMAN = range(4)
 EXPORTS = [
     "if_bpf_design", "if_bpf_design_complex", "if_fir_init", "if_fir_init_complex", "if_fir_destroy", "if_fir_reset", "if_fir_set_backend", "if_fir_get_backend",
     "if_fir_set_tuning", "if_fir_set_input_format", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
-    "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_time_device", "if_fir_dev_alloc",
-    "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info", "if_fir_debug_stamps",
+    "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_dev_alloc",
+    "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info",
     "if_fir_set_nco", "if_fir_get_nco", "if_fir_channelizer_process_device", "if_fir_host_alloc", "if_fir_host_free",
-    "if_fir_debug_fft_tables", "if_fir_debug_fft_schedule", "if_fir_power_device",
+    "if_fir_power_device",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
-    "if_fir_mc_set_chunk_samples", "if_fir_mc_debug_plan",
+    "if_fir_mc_set_chunk_samples",
 ]
+# every symbol include/if_fir_debug.h declares: exported by libif_fir_dev.so only
+DEV_EXPORTS = ["if_fir_time_device", "if_fir_debug_stamps", "if_fir_debug_fft_tables", "if_fir_debug_fft_schedule",
+               "if_fir_mc_debug_plan"]
 MC_ID_BYTES = 128
 
 
@@ -31,18 +40,26 @@ class IfFirError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
 def lib():
-    """Load libif_fir.so (raises if it has not been built: there is no fallback)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise IfFirError("libif_fir.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
-                         % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+    """Load libif_fir.so, the product (raises if it has not been built: there is no fallback)."""
+    return _load(LIB_PATH, False)
+
+
+def dev_lib():
+    """Load libif_fir_dev.so: the product's code plus the development hooks of include/if_fir_debug.h."""
+    return _load(DEV_LIB_PATH, True)
+
+
+def _load(path, dev):
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise IfFirError("%s is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                         % (os.path.basename(path), path))
+    L = ctypes.CDLL(path)
     u8, u32, u64, i32, vp = ctypes.c_uint8, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p
     f32p = ctypes.POINTER(ctypes.c_float)
     L.if_bpf_design.argtypes = [f32p, u32, ctypes.c_double, ctypes.c_double, u32]
@@ -79,8 +96,6 @@ def lib():
     L.if_fir_process_device.restype = u8
     L.if_fir_synth_device.argtypes = [vp, vp, u64, u64, u32]
     L.if_fir_synth_device.restype = u8
-    L.if_fir_time_device.argtypes = [vp, vp, vp, u64, u32, u32, f32p]
-    L.if_fir_time_device.restype = u8
     L.if_fir_dev_alloc.argtypes = [vp, ctypes.POINTER(vp), u64]
     L.if_fir_dev_alloc.restype = u8
     L.if_fir_dev_free.argtypes = [vp, vp]
@@ -89,8 +104,6 @@ def lib():
     L.if_fir_dev_upload.restype = u8
     L.if_fir_dev_download.argtypes = [vp, vp, vp, u64]
     L.if_fir_dev_download.restype = u8
-    L.if_fir_debug_stamps.argtypes = [vp, ctypes.POINTER(u64), u32]
-    L.if_fir_debug_stamps.restype = u32
     L.if_fir_device_info.argtypes = [vp, ctypes.c_char_p, u32]
     L.if_fir_device_info.restype = u8
     L.if_fir_set_nco.argtypes = [vp, ctypes.c_double]
@@ -104,10 +117,6 @@ def lib():
     L.if_fir_host_alloc.restype = u8
     L.if_fir_host_free.argtypes = [vp, vp]
     L.if_fir_host_free.restype = u8
-    L.if_fir_debug_fft_tables.argtypes = [f32p, u32, u32, u32, u32, f32p, u32]
-    L.if_fir_debug_fft_tables.restype = u32
-    L.if_fir_debug_fft_schedule.argtypes = [u64, u32, ctypes.POINTER(ctypes.c_int64)]
-    L.if_fir_debug_fft_schedule.restype = u8
     L.if_fir_power_device.argtypes = [vp, vp, u64, ctypes.POINTER(ctypes.c_double)]
     L.if_fir_power_device.restype = u8
     u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -131,9 +140,18 @@ def lib():
     L.if_fir_mc_last_error.restype = ctypes.c_char_p
     L.if_fir_mc_set_chunk_samples.argtypes = [vp, u64]
     L.if_fir_mc_set_chunk_samples.restype = u8
-    L.if_fir_mc_debug_plan.argtypes = [u32, u32, u32, u64, u32, u32, u64, u64, ctypes.POINTER(u64), u32]
-    L.if_fir_mc_debug_plan.restype = u32
-    _lib = L
+    if dev:
+        L.if_fir_time_device.argtypes = [vp, vp, vp, u64, u32, u32, f32p]
+        L.if_fir_time_device.restype = u8
+        L.if_fir_debug_stamps.argtypes = [vp, ctypes.POINTER(u64), u32]
+        L.if_fir_debug_stamps.restype = u32
+        L.if_fir_debug_fft_tables.argtypes = [f32p, u32, u32, u32, u32, f32p, u32]
+        L.if_fir_debug_fft_tables.restype = u32
+        L.if_fir_debug_fft_schedule.argtypes = [u64, u32, ctypes.POINTER(ctypes.c_int64)]
+        L.if_fir_debug_fft_schedule.restype = u8
+        L.if_fir_mc_debug_plan.argtypes = [u32, u32, u32, u64, u32, u32, u32, u64, u64, ctypes.POINTER(u64), u32]
+        L.if_fir_mc_debug_plan.restype = u32
+    _libs[path] = L
     return L
 
 
@@ -160,7 +178,8 @@ def bpf_design_complex(taps, centre=0.2, bandwidth=0.1, window=WINDOW_BLACKMAN):
 class IfFir:
     """One if_fir_ctx_t.  Methods mirror the C entry points."""
 
-    def __init__(self, taps, decimation=1, max_samples=1 << 20, device=0, backend=None, complex_taps=False):
+    def __init__(self, taps, decimation=1, max_samples=1 << 20, device=0, backend=None, complex_taps=False, dev=False):
+        self._L = dev_lib() if dev else lib()
         taps = np.asarray(taps)
         if np.iscomplexobj(taps):
             taps = np.ascontiguousarray(taps.astype(np.complex64)).view(np.float32)
@@ -170,24 +189,24 @@ class IfFir:
         self.taps = taps
         self.decimation = int(decimation)
         if complex_taps:
-            ok = lib().if_fir_init_complex(ctypes.byref(self._ctx), _f32p(taps), taps.size // 2, self.decimation,
+            ok = self._L.if_fir_init_complex(ctypes.byref(self._ctx), _f32p(taps), taps.size // 2, self.decimation,
                                            int(max_samples), int(device))
         else:
-            ok = lib().if_fir_init(ctypes.byref(self._ctx), _f32p(taps), taps.size, self.decimation,
+            ok = self._L.if_fir_init(ctypes.byref(self._ctx), _f32p(taps), taps.size, self.decimation,
                                    int(max_samples), int(device))
         if not ok:
             self._ctx = ctypes.c_void_p()
-            raise IfFirError(lib().if_fir_last_error(None).decode())
+            raise IfFirError(self._L.if_fir_last_error(None).decode())
         if backend is not None:
             self.set_backend(backend)
 
     def _check(self, ok):
         if not ok:
-            raise IfFirError(lib().if_fir_last_error(self._ctx).decode())
+            raise IfFirError(self._L.if_fir_last_error(self._ctx).decode())
 
     def close(self):
         if self._ctx:
-            lib().if_fir_destroy(self._ctx)
+            self._L.if_fir_destroy(self._ctx)
             self._ctx = ctypes.c_void_p()
 
     def __del__(self):
@@ -203,38 +222,38 @@ class IfFir:
         self.close()
 
     def reset(self):
-        self._check(lib().if_fir_reset(self._ctx))
+        self._check(self._L.if_fir_reset(self._ctx))
 
     def set_backend(self, backend):
-        self._check(lib().if_fir_set_backend(self._ctx, int(backend)))
+        self._check(self._L.if_fir_set_backend(self._ctx, int(backend)))
 
     def get_backend(self):
-        return int(lib().if_fir_get_backend(self._ctx))
+        return int(self._L.if_fir_get_backend(self._ctx))
 
     def set_input_format(self, fmt):
-        self._check(lib().if_fir_set_input_format(self._ctx, int(fmt)))
+        self._check(self._L.if_fir_set_input_format(self._ctx, int(fmt)))
         self._i16 = (int(fmt) == INPUT_I16)
 
     def set_nco(self, freq):
         """if_fir_set_nco(): mix the input with exp(-j 2 pi f a) ahead of the filter (SPEC §3.2); 0 = off."""
-        self._check(lib().if_fir_set_nco(self._ctx, float(freq)))
+        self._check(self._L.if_fir_set_nco(self._ctx, float(freq)))
 
     def get_nco(self):
         f = ctypes.c_double(0.0)
-        self._check(lib().if_fir_get_nco(self._ctx, ctypes.byref(f)))
+        self._check(self._L.if_fir_get_nco(self._ctx, ctypes.byref(f)))
         return float(f.value)
 
     def power_device(self, dev_iq, samples):
         """if_fir_power_device(): mean(|y|^2) of a device IQ buffer."""
         p = ctypes.c_double(0.0)
-        self._check(lib().if_fir_power_device(self._ctx, ctypes.c_void_p(int(dev_iq)), int(samples), ctypes.byref(p)))
+        self._check(self._L.if_fir_power_device(self._ctx, ctypes.c_void_p(int(dev_iq)), int(samples), ctypes.byref(p)))
         return float(p.value)
 
     def host_alloc(self, count, dtype=np.float32):
         """if_fir_host_alloc(): a page-locked numpy array of `count` elements (free it with host_free(array))."""
         dtype = np.dtype(dtype)
         p = ctypes.c_void_p(None)
-        self._check(lib().if_fir_host_alloc(self._ctx, ctypes.byref(p), int(count) * dtype.itemsize))
+        self._check(self._L.if_fir_host_alloc(self._ctx, ctypes.byref(p), int(count) * dtype.itemsize))
         buf = (ctypes.c_char * (int(count) * dtype.itemsize)).from_address(p.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(count))
         self._pinned = getattr(self, "_pinned", {})
@@ -243,13 +262,13 @@ class IfFir:
 
     def host_free(self, arr):
         p = self._pinned.pop(arr.ctypes.data)
-        self._check(lib().if_fir_host_free(self._ctx, ctypes.c_void_p(p)))
+        self._check(self._L.if_fir_host_free(self._ctx, ctypes.c_void_p(p)))
 
     def process_into(self, iq, out):
         """if_fir_process() with caller-provided host arrays (e.g. from host_alloc); returns the output sample count."""
         n = iq.size // 2
         m = ctypes.c_uint64(0)
-        self._check(lib().if_fir_process(self._ctx, ctypes.cast(iq.ctypes.data, ctypes.POINTER(ctypes.c_float)),
+        self._check(self._L.if_fir_process(self._ctx, ctypes.cast(iq.ctypes.data, ctypes.POINTER(ctypes.c_float)),
                                          _f32p(out), n, ctypes.byref(m)))
         return int(m.value)
 
@@ -259,25 +278,25 @@ class IfFir:
         sl = (ctypes.c_uint32 * k)(*[int(v) for v in slots])
         po = (ctypes.c_void_p * k)(*[ctypes.c_void_p(int(p)) for p in dev_outs])
         m = ctypes.c_uint64(0)
-        self._check(lib().if_fir_channelizer_process_device(self._ctx, k, sl, ctypes.c_void_p(int(dev_in)), po,
+        self._check(self._L.if_fir_channelizer_process_device(self._ctx, k, sl, ctypes.c_void_p(int(dev_in)), po,
                                                             int(samples), ctypes.byref(m)))
         return int(m.value)
 
     def set_tuning(self, variant):
-        self._check(lib().if_fir_set_tuning(self._ctx, int(variant)))
+        self._check(self._L.if_fir_set_tuning(self._ctx, int(variant)))
 
     def set_stream(self, stream_handle):
-        self._check(lib().if_fir_set_stream(self._ctx, ctypes.c_void_p(stream_handle or None)))
+        self._check(self._L.if_fir_set_stream(self._ctx, ctypes.c_void_p(stream_handle or None)))
 
     def synchronize(self):
-        self._check(lib().if_fir_synchronize(self._ctx))
+        self._check(self._L.if_fir_synchronize(self._ctx))
 
     def out_count(self, samples):
-        return int(lib().if_fir_out_count(self._ctx, int(samples)))
+        return int(self._L.if_fir_out_count(self._ctx, int(samples)))
 
     def device_info(self):
         buf = ctypes.create_string_buffer(256)
-        self._check(lib().if_fir_device_info(self._ctx, buf, 256))
+        self._check(self._L.if_fir_device_info(self._ctx, buf, 256))
         return buf.value.decode()
 
     def process(self, iq):
@@ -294,7 +313,7 @@ class IfFir:
         m = ctypes.c_uint64(0)
         dummy = np.zeros(2, dtype=np.float32)
         src = iq if n else dummy
-        self._check(lib().if_fir_process(self._ctx, ctypes.cast(src.ctypes.data, ctypes.POINTER(ctypes.c_float)),
+        self._check(self._L.if_fir_process(self._ctx, ctypes.cast(src.ctypes.data, ctypes.POINTER(ctypes.c_float)),
                                          _f32p(out if out.size else dummy), n, ctypes.byref(m)))
         assert m.value * 2 == out.size
         return out
@@ -302,46 +321,47 @@ class IfFir:
     def process_device(self, dev_in, dev_out, samples):
         """if_fir_process_device(): raw device pointers (ints), asynchronous. Returns the output sample count."""
         m = ctypes.c_uint64(0)
-        self._check(lib().if_fir_process_device(self._ctx, ctypes.c_void_p(dev_in), ctypes.c_void_p(dev_out),
+        self._check(self._L.if_fir_process_device(self._ctx, ctypes.c_void_p(dev_in), ctypes.c_void_p(dev_out),
                                                 int(samples), ctypes.byref(m)))
         return int(m.value)
 
     def synth_device(self, dev_iq, first, samples, channel=0):
-        self._check(lib().if_fir_synth_device(self._ctx, ctypes.c_void_p(dev_iq), int(first), int(samples),
+        self._check(self._L.if_fir_synth_device(self._ctx, ctypes.c_void_p(dev_iq), int(first), int(samples),
                                               int(channel)))
 
     def time_device(self, dev_in, dev_out, samples, warmup=3, reps=10):
+        """if_fir_time_device() (development library: construct with dev=True)."""
         ms = ctypes.c_float(0)
-        self._check(lib().if_fir_time_device(self._ctx, ctypes.c_void_p(dev_in), ctypes.c_void_p(dev_out),
+        self._check(self._L.if_fir_time_device(self._ctx, ctypes.c_void_p(dev_in), ctypes.c_void_p(dev_out),
                                              int(samples), int(warmup), int(reps), ctypes.byref(ms)))
         return float(ms.value)
 
     def debug_stamps(self, waves=None):
         """Arm (waves=None) or fetch the per-wave diagnostic stamps of the last persistent-kernel launch."""
         if waves is None:
-            lib().if_fir_debug_stamps(self._ctx, None, 0)
+            self._L.if_fir_debug_stamps(self._ctx, None, 0)
             return None
         buf = np.zeros(4 * waves, dtype=np.uint64)
-        n = lib().if_fir_debug_stamps(self._ctx, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), buf.size)
+        n = self._L.if_fir_debug_stamps(self._ctx, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), buf.size)
         return buf[:n].reshape(-1, 4)
 
     # device memory helpers (pure C hosts use these instead of HIP headers)
     def dev_alloc(self, nbytes):
         p = ctypes.c_void_p()
-        self._check(lib().if_fir_dev_alloc(self._ctx, ctypes.byref(p), int(nbytes)))
+        self._check(self._L.if_fir_dev_alloc(self._ctx, ctypes.byref(p), int(nbytes)))
         return p.value
 
     def dev_free(self, ptr):
-        self._check(lib().if_fir_dev_free(self._ctx, ctypes.c_void_p(ptr)))
+        self._check(self._L.if_fir_dev_free(self._ctx, ctypes.c_void_p(ptr)))
 
     def dev_upload(self, ptr, host):
         host = np.ascontiguousarray(host)
-        self._check(lib().if_fir_dev_upload(self._ctx, ctypes.c_void_p(ptr), host.ctypes.data_as(ctypes.c_void_p),
+        self._check(self._L.if_fir_dev_upload(self._ctx, ctypes.c_void_p(ptr), host.ctypes.data_as(ctypes.c_void_p),
                                             host.nbytes))
 
     def dev_download(self, ptr, nbytes, dtype=np.float32):
         host = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
-        self._check(lib().if_fir_dev_download(self._ctx, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
+        self._check(self._L.if_fir_dev_download(self._ctx, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
                                               host.nbytes))
         return host
 
@@ -354,7 +374,7 @@ def debug_fft_tables(taps, decimation, complex_taps=False, nco_delta=0):
     taps = np.ascontiguousarray(taps, dtype=np.float32)
     t = taps.size // 2 if complex_taps else taps.size
     out = np.zeros(FFT_TABLE_FLOATS, dtype=np.float32)
-    n = lib().if_fir_debug_fft_tables(_f32p(taps), t, 1 if complex_taps else 0, int(decimation), int(nco_delta) & 0xFFFFFFFF,
+    n = dev_lib().if_fir_debug_fft_tables(_f32p(taps), t, 1 if complex_taps else 0, int(decimation), int(nco_delta) & 0xFFFFFFFF,
                                       _f32p(out), out.size)
     if n != FFT_TABLE_FLOATS:
         raise IfFirError("if_fir_debug_fft_tables: (taps=%d, decimation=%d) is not served by the overlap-save kernel" % (t, decimation))
@@ -367,7 +387,7 @@ def debug_fft_schedule(nblocks, workgroups=256):
     """if_fir_debug_fft_schedule(): block-queue layout of an overlap-save launch (host-only): RA = blocks per group,
     nA = groups, RB = static groups per workgroup, nB = 0, tickets = bound of the global counter, wgs = workgroups."""
     out = (ctypes.c_int64 * 6)()
-    if not lib().if_fir_debug_fft_schedule(int(nblocks), int(workgroups), out):
+    if not dev_lib().if_fir_debug_fft_schedule(int(nblocks), int(workgroups), out):
         raise IfFirError("if_fir_debug_fft_schedule: bad arguments")
     return dict(zip(("RA", "nA", "RB", "nB", "tickets", "wgs"), [int(v) for v in out]))
 
@@ -381,14 +401,14 @@ MC_CHUNK_UNIT = 215040
 MC_NEVER_SPLIT = (1 << 64) - 1
 
 
-def mc_debug_plan(world, channels, rank, samples, in_bytes=8, decimation=1, consumed=0, chunk=0):
+def mc_debug_plan(world, channels, rank, samples, in_bytes=8, decimation=1, consumed=0, chunk=0, taps=255):
     """if_fir_mc_debug_plan(): list of dict(kind, phase, group, peer, channel, chunk, offset, bytes) in posting order
     (host-only; chunk=0 means one piece here)."""
-    n = lib().if_fir_mc_debug_plan(int(world), int(channels), int(rank), int(samples), int(in_bytes), int(decimation),
-                                   int(consumed), int(chunk), None, 0)
+    n = dev_lib().if_fir_mc_debug_plan(int(world), int(channels), int(rank), int(samples), int(in_bytes), int(taps),
+                                       int(decimation), int(consumed), int(chunk), None, 0)
     buf = np.zeros(8 * max(n, 1), dtype=np.uint64)
-    lib().if_fir_mc_debug_plan(int(world), int(channels), int(rank), int(samples), int(in_bytes), int(decimation),
-                               int(consumed), int(chunk), buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n)
+    dev_lib().if_fir_mc_debug_plan(int(world), int(channels), int(rank), int(samples), int(in_bytes), int(taps), int(decimation),
+                                   int(consumed), int(chunk), buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n)
     keys = ("kind", "phase", "group", "peer", "channel", "chunk", "offset", "bytes")
     return [dict(zip(keys, (int(v) for v in buf[8 * i:8 * i + 8]))) for i in range(n)]
 
@@ -404,7 +424,8 @@ def mc_unique_id():
 class IfFirMc:
     """One if_fir_mc_ctx_t: channel c -> rank c mod world, inputs/outputs on rank 0's GPU (see include/if_fir.h)."""
 
-    def __init__(self, taps, decimation, max_samples, device=0, rank=0, world=1, unique_id=None):
+    def __init__(self, taps, decimation, max_samples, device=0, rank=0, world=1, unique_id=None, dev=False):
+        self._L = dev_lib() if dev else lib()
         taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float32))
         if taps.ndim != 2:
             raise IfFirError("taps must be a (channels, taps) array")
@@ -413,36 +434,36 @@ class IfFirMc:
         idbuf = None
         if unique_id is not None:
             idbuf = (ctypes.c_uint8 * MC_ID_BYTES).from_buffer_copy(bytes(unique_id))
-        ok = lib().if_fir_mc_init(ctypes.byref(self._ctx), self.channels, _f32p(taps), int(taps.shape[1]),
+        ok = self._L.if_fir_mc_init(ctypes.byref(self._ctx), self.channels, _f32p(taps), int(taps.shape[1]),
                                   int(decimation), int(max_samples), int(device), self.rank, self.world, idbuf)
         if not ok:
             self._ctx = ctypes.c_void_p(None)
-            raise IfFirError(lib().if_fir_mc_last_error(None).decode())
+            raise IfFirError(self._L.if_fir_mc_last_error(None).decode())
 
     def _check(self, ok):
         if not ok:
-            raise IfFirError(lib().if_fir_mc_last_error(self._ctx).decode())
+            raise IfFirError(self._L.if_fir_mc_last_error(self._ctx).decode())
 
     def reset(self):
-        self._check(lib().if_fir_mc_reset(self._ctx))
+        self._check(self._L.if_fir_mc_reset(self._ctx))
 
     def set_input_format(self, fmt):
-        self._check(lib().if_fir_mc_set_input_format(self._ctx, int(fmt)))
+        self._check(self._L.if_fir_mc_set_input_format(self._ctx, int(fmt)))
 
     def set_chunk_samples(self, chunk):
         """0 = default chunk, MC_NEVER_SPLIT = whole calls, else a multiple of MC_CHUNK_UNIT samples."""
-        self._check(lib().if_fir_mc_set_chunk_samples(self._ctx, int(chunk)))
+        self._check(self._L.if_fir_mc_set_chunk_samples(self._ctx, int(chunk)))
 
     def channel_ctx(self, channel):
         """Raw if_fir_ctx_t* (int) of a channel this rank owns, else None."""
-        return lib().if_fir_mc_channel_ctx(self._ctx, int(channel))
+        return self._L.if_fir_mc_channel_ctx(self._ctx, int(channel))
 
     def set_backend(self, backend):
         """if_fir_set_backend() on every channel this rank owns."""
         for c in range(self.channels):
             h = self.channel_ctx(c)
-            if h and not lib().if_fir_set_backend(h, int(backend)):
-                raise IfFirError(lib().if_fir_last_error(h).decode())
+            if h and not self._L.if_fir_set_backend(h, int(backend)):
+                raise IfFirError(self._L.if_fir_last_error(h).decode())
 
     def process_device(self, dev_in, dev_out, samples):
         """if_fir_mc_process_device(): lists of device pointers (ints) on rank 0, None elsewhere.  Returns the
@@ -452,12 +473,12 @@ class IfFirMc:
         if dev_in is not None:
             pin = (ctypes.c_void_p * self.channels)(*[ctypes.c_void_p(int(p)) for p in dev_in])
             pout = (ctypes.c_void_p * self.channels)(*[ctypes.c_void_p(int(p)) for p in dev_out])
-        self._check(lib().if_fir_mc_process_device(self._ctx, pin, pout, int(samples), ctypes.byref(m)))
+        self._check(self._L.if_fir_mc_process_device(self._ctx, pin, pout, int(samples), ctypes.byref(m)))
         return int(m.value)
 
     def close(self):
         if self._ctx:
-            lib().if_fir_mc_destroy(self._ctx)
+            self._L.if_fir_mc_destroy(self._ctx)
             self._ctx = ctypes.c_void_p(None)
 
     def __enter__(self):

@@ -10,7 +10,9 @@ import sys
 import threading
 
 fake, world, channels = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-inject = len(sys.argv) > 4 and sys.argv[4] == "inject"   # rank 1's first channel fails its first filter call
+mode = sys.argv[4] if len(sys.argv) > 4 else ""
+inject = mode == "inject"       # rank 1's first channel fails its first filter call (development library: test hook)
+offphase = mode.startswith("offphase")   # "offphase<D>": call lengths that leave the decimation phase != 0
 os.environ["IF_FIR_RCCL_LIBRARY"] = fake
 os.environ["IF_FIR_DEBUG"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,8 +24,10 @@ import __graft_entry__ as g  # noqa: E402
 
 fir = g.load_pkg().if_fir
 torch.cuda.set_device(0)
-d, t = 4, 255
-calls = [700_000, 300_004]                      # two calls: streaming state per channel, phase 0 at every chunk boundary
+d, t = (int(mode[8:]) if offphase and mode[8:] else 4), 255
+# two calls: streaming state per channel.  Default: phase 0 at every chunk boundary; offphase: the second call starts at
+# phase 1 and both calls are cut into chunks (the first chunk of an off-phase call absorbs the phase when D = 4)
+calls = [700_001, 500_003] if offphase else [700_000, 300_004]
 nmax = max(calls)
 taps = np.stack([fir.bpf_design(t, 0.02 + 0.04 * c, 0.05 + 0.04 * c) for c in range(channels)])
 uid = fir.mc_unique_id()
@@ -45,14 +49,14 @@ barrier = threading.Barrier(world)
 def rank_main(rank):
     try:
         torch.cuda.set_device(0)
-        with fir.IfFirMc(taps, d, nmax, device=0, rank=rank, world=world, unique_id=uid) as mc:
+        with fir.IfFirMc(taps, d, nmax, device=0, rank=rank, world=world, unique_id=uid, dev=inject) as mc:
             mc.set_chunk_samples(fir.MC_CHUNK_UNIT)        # 215040 samples: four chunks in the first call, two in the second
             if inject:
                 # an owner's filter fails in the middle of the protocol: nobody may hang, the owner and the root must both
                 # report it, the others succeed; after a reset on every rank the front works again
                 if rank == 1:
                     h = mc.channel_ctx(1)
-                    assert h and fir.lib().if_fir_set_tuning(h, 4000)
+                    assert h and fir.dev_lib().if_fir_set_tuning(h, 4000)
                 barrier.wait()
                 try:
                     mc.process_device([x.data_ptr() for x in ins[0]] if rank == 0 else None,

@@ -186,7 +186,7 @@ def test_device_api_canaries_and_errors(fir, oracle, torch_cuda):
     xin = torch.from_numpy(x).cuda()
     out = torch.full((2 * m + 2 * guard,), 12345.0, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    with fir.IfFir(taps, d, n, backend=fir.BACKEND_HIP_DIRECT) as f:
+    with fir.IfFir(taps, d, n, backend=fir.BACKEND_HIP_DIRECT, dev=True) as f:
         with pytest.raises(fir.IfFirError, match="aligned"):
             f.process_device(xin.data_ptr() + 4, out.data_ptr(), n - 1)
         got = f.process_device(xin.data_ptr(), out.data_ptr() + 4 * guard, n)
@@ -275,7 +275,7 @@ def test_fft_backend_run_queue_on_small_grid(fir, oracle, t, d, i16):
     else:
         x = oracle.synth_iq(n, 21)
     ref = oracle.fir_f64(taps, x, d)
-    with fir.IfFir(taps, d, n) as f:
+    with fir.IfFir(taps, d, n, dev=True) as f:
         if i16:
             f.set_input_format(fir.INPUT_I16)
         f.set_backend(fir.BACKEND_HIP_FFT)
@@ -297,11 +297,17 @@ def test_fft_backend_run_queue_on_small_grid(fir, oracle, t, d, i16):
 
 
 def test_diagnostic_variants_need_the_debug_switch(fir, gpu_ok):
-    """Tuning variants 1000..1999 are timing diagnostics that skip loads or stores (wrong results): the shipped ABI
-    refuses them unless the process runs with IF_FIR_DEBUG=1; variants that only change speed stay open."""
+    """The product library takes schedule variants 0..9 only; the development library (include/if_fir_debug.h) has the
+    grid limits and, with IF_FIR_DEBUG=1, the diagnostic launches that skip loads or stores (wrong results)."""
     old = os.environ.pop("IF_FIR_DEBUG", None)
     try:
         with fir.IfFir(fir.bpf_design(255), 4, 1000) as f:
+            for v in (10, 1001, 2003, 4000, 1000008):
+                with pytest.raises(fir.IfFirError, match="development"):
+                    f.set_tuning(v)
+            f.set_tuning(3)
+            f.set_tuning(0)
+        with fir.IfFir(fir.bpf_design(255), 4, 1000, dev=True) as f:
             with pytest.raises(fir.IfFirError, match="diagnostic"):
                 f.set_tuning(1001)
             f.set_tuning(2003)
@@ -502,18 +508,21 @@ def test_multi_channel_front_one_rank(fir, oracle, torch_cuda):
 
 def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
     """The multi-channel front moves and filters a call in chunks (multiples of 215040 samples = lcm of the overlap-save
-    block advances) and the contexts keep a whole block overlap of history, so the blocks of a chunked call start where
-    those of the unsplit call start and see the same samples: with the decimation phase at 0 (call lengths that are
-    multiples of the decimation) ANY chunking is bit-identical to no chunking.  With a phase p != 0 the last block of
-    a chunk would need p samples of the next chunk, which a streaming filter does not have: zeros stand in, the outputs
-    agree to rounding (checked against the bound, not bit for bit).  One rank, three channels, two calls."""
+    block advances, rounded up to a multiple of twice the decimation) and the contexts keep a whole block overlap of
+    history, so the blocks of a chunked call start where those of the unsplit call start and see the same samples: ANY
+    chunking is bit-identical to no chunking, at ANY decimation phase (round 3: where the block grid follows the phase,
+    decimation 4, the first chunk of an off-phase call is that many samples longer, so that no block of a chunk reaches
+    past the chunk's end; the pieces then start at odd sample offsets, which the overlap-save kernel accepts).  One rank,
+    three channels, two calls; D = 11 (chunks of 11 x 215040 samples) on a longer stream."""
     torch = torch_cuda
-    n = 1_000_008
-    for t, d, first in ((255, 4, 600_000), (1023, 1, 600_001), (511, 3, 600_000), (2047, 4, 600_000), (255, 4, 600_002)):
+    cases = [(255, 4, 600_000, 1_000_008), (1023, 1, 600_001, 1_000_008), (511, 3, 600_001, 1_000_008),
+             (2047, 4, 600_003, 1_000_008), (255, 4, 600_002, 1_000_008), (255, 4, 600_001, 1_000_007),
+             (255, 7, 600_003, 1_000_008), (3075, 4, 600_001, 1_000_008), (255, 11, 2_500_003, 7_400_000)]
+    for t, d, first, n in cases:
         cuts = [0, first, n]
-        exact = first % d == 0
-        taps = np.stack([fir.bpf_design(t, 0.15, 0.25), fir.bpf_design(t, 0.02, 0.08), fir.bpf_design(t, 0.3, 0.45)])
-        dev_in = [torch.from_numpy(oracle.synth_iq(n, 40 + c)).cuda() for c in range(3)]
+        nch = 3 if n < 2_000_000 else 1
+        taps = np.stack([fir.bpf_design(t, 0.15, 0.25), fir.bpf_design(t, 0.02, 0.08), fir.bpf_design(t, 0.3, 0.45)][:nch])
+        dev_in = [torch.from_numpy(oracle.synth_iq(n, 40 + c)).cuda() for c in range(nch)]
         results = {}
         with fir.IfFirMc(taps, d, n) as mc:
             with pytest.raises(fir.IfFirError, match="multiple"):
@@ -521,29 +530,61 @@ def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
             for chunk in (fir.MC_NEVER_SPLIT, fir.MC_CHUNK_UNIT, 2 * fir.MC_CHUNK_UNIT, 0):
                 mc.set_chunk_samples(chunk)
                 mc.reset()
-                parts = [[] for _ in range(3)]
+                parts = [[] for _ in range(nch)]
                 for a, b in zip(cuts[:-1], cuts[1:]):
                     m_exp = oracle.out_count(a, b - a, d)
-                    outs = [torch.full((2 * m_exp + 8,), 7.0, dtype=torch.float32, device="cuda") for _ in range(3)]
+                    outs = [torch.full((2 * m_exp + 8,), 7.0, dtype=torch.float32, device="cuda") for _ in range(nch)]
                     pieces = [x[2 * a:2 * b].clone() for x in dev_in]
                     torch.cuda.synchronize()
                     assert mc.process_device([p.data_ptr() for p in pieces], [o.data_ptr() for o in outs], b - a) == m_exp
-                    for c in range(3):
+                    for c in range(nch):
                         o = outs[c].cpu().numpy()
                         assert np.all(o[2 * m_exp:] == 7.0)
                         parts[c].append(o[:2 * m_exp])
                 results[chunk] = [np.concatenate(p) for p in parts]
         ref = results[fir.MC_NEVER_SPLIT]
-        scale = max(float(np.abs(r).max()) for r in ref)
         for chunk, res in results.items():
-            for c in range(3):
-                if exact:
-                    assert np.array_equal(res[c], ref[c]), (t, d, chunk, c)
-                else:
-                    assert float(np.abs(res[c] - ref[c]).max()) <= 2e-6 * scale, (t, d, chunk, c)
-        for res in results.values():
-            l2, mx = oracle.err_metrics(res[1], oracle.fir_f64(taps[1], dev_in[1].cpu().numpy(), d))
-            assert l2 <= TOL and mx <= TOL, (t, d, l2, mx)
+            for c in range(nch):
+                assert np.array_equal(res[c], ref[c]), (t, d, first, chunk, c)
+        l2, mx = oracle.err_metrics(ref[nch - 1], oracle.fir_f64(taps[nch - 1], dev_in[nch - 1].cpu().numpy(), d))
+        assert l2 <= TOL and mx <= TOL, (t, d, l2, mx)
+
+
+def test_overlap_save_backend_takes_sample_aligned_pointers(fir, oracle, torch_cuda):
+    """The overlap-save kernel moves one sample per lane: input and output pointers need only be aligned to a sample (8
+    bytes; 4 for int16 input), which the chunked multi-channel front relies on; the results are those of aligned buffers."""
+    torch = torch_cuda
+    taps = fir.bpf_design(255)
+    n = 300_001
+    x = oracle.synth_iq(n + 1, 77)
+    xd = torch.from_numpy(x).cuda()
+    for d in (1, 4, 5):
+        with fir.IfFir(taps, d, 0) as f:
+            assert f.get_backend() == fir.BACKEND_HIP_FFT
+            m = f.out_count(n)
+            ref = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+            aligned = xd[2:2 * n + 2].clone()
+            f.process_device(aligned.data_ptr(), ref.data_ptr(), n)
+            f.reset()
+            out = torch.full((2 * m + 6,), 9.0, dtype=torch.float32, device="cuda")
+            assert f.process_device(xd.data_ptr() + 8, out.data_ptr() + 8, n) == m       # both 8 mod 16
+            f.synchronize()
+            assert torch.equal(out[2:2 * m + 2], ref) and bool((out[:2] == 9.0).all()) and bool((out[2 * m + 2:] == 9.0).all())
+            with pytest.raises(fir.IfFirError, match="aligned"):
+                f.process_device(xd.data_ptr() + 4, out.data_ptr(), n)
+    xi = (np.clip(x, -1, 1) * 20000).astype(np.int16)
+    xid = torch.from_numpy(xi).cuda()
+    with fir.IfFir(taps, 4, 0) as f:
+        f.set_input_format(fir.INPUT_I16)
+        m = f.out_count(n)
+        ref = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        aligned = xid[2:2 * n + 2].clone()
+        f.process_device(aligned.data_ptr(), ref.data_ptr(), n)
+        f.reset()
+        out = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        f.process_device(xid.data_ptr() + 4, out.data_ptr(), n)                           # 4 mod 16
+        f.synchronize()
+        assert torch.equal(out, ref)
 
 
 def test_multi_channel_bootstrap_id(fir, gpu_ok):
@@ -650,7 +691,7 @@ def test_uniform_filter_bank(fir, oracle, torch_cuda, t):
     slots = [0, 3, 5, 15, 8, 3, 10]
     refs = [oracle.fir_nco_f64(taps, x, 4, (s << 28) & 0xFFFFFFFF) for s in slots]
     cuts = [0, 1, 6, 4103, 40_001, 40_004, n]
-    with fir.IfFir(taps, 4, 0) as f:
+    with fir.IfFir(taps, 4, 0, dev=True) as f:
         f.set_backend(fir.BACKEND_HIP_FFT)
         for tuning in (0, 2001):
             f.set_tuning(tuning)
@@ -774,7 +815,7 @@ def test_fft_backend_any_decimation(fir, oracle, t, d):
     n = 120_011
     x = np.concatenate([oracle.synth_iq(n // 2, 23), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
     ref = oracle.fir_f64(taps, x, d)
-    with fir.IfFir(taps, d, n) as f:
+    with fir.IfFir(taps, d, n, dev=True) as f:
         f.set_backend(fir.BACKEND_HIP_FFT)
         y = f.process(x)
         assert y.shape == ref.shape
@@ -843,7 +884,7 @@ def test_fft_backend_long_filters(fir, oracle, t, d):
     n = 70_001
     x = np.concatenate([oracle.synth_iq(n // 2, 29), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
     ref = oracle.fir_f64(taps, x, d)
-    with fir.IfFir(taps, d, n) as f:
+    with fir.IfFir(taps, d, n, dev=True) as f:
         assert f.get_backend() == fir.BACKEND_HIP_FFT
         for tuning in (0, 2001):
             f.set_tuning(tuning)
@@ -878,7 +919,7 @@ def test_fft_backend_two_partitions(fir, oracle, t, d):
     n = 90_001
     x = np.concatenate([oracle.synth_iq(n // 2, 33), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
     ref = oracle.fir_f64(taps, x, d)
-    with fir.IfFir(taps, d, n) as f:
+    with fir.IfFir(taps, d, n, dev=True) as f:
         assert f.get_backend() == fir.BACKEND_HIP_FFT
         for tuning in (0, 2001):
             f.set_tuning(tuning)
@@ -998,7 +1039,7 @@ def test_block_queue_counters_alternate_over_many_launches(fir, oracle):
     taps = fir.bpf_design(255)
     x = oracle.synth_iq(n, 71)
     cuts = [0, 100_000, 250_000, 250_004, 400_001, 500_003, 650_000, n]
-    with fir.IfFir(taps, 4, n) as f:
+    with fir.IfFir(taps, 4, n, dev=True) as f:
         assert f.get_backend() == fir.BACKEND_HIP_FFT
         # (the same cuts everywhere: where a block starts decides the last bits of an FFT result)
         ref = np.concatenate([f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])

@@ -17,6 +17,18 @@ def test_library_exports_every_declared_symbol(fir):
     lib = fir.lib()
     for name in declared:
         assert hasattr(lib, name), name
+    # the development hooks (include/if_fir_debug.h) exist in libif_fir_dev.so only: the product exports none of them
+    import subprocess
+    dbg = open(os.path.join(ROOT, "include", "if_fir_debug.h")).read()
+    dev_declared = set(re.findall(r"^\w+ \*?(if_fir_[a-z_]+)\s*\(", dbg, re.M))
+    assert dev_declared == set(fir.DEV_EXPORTS), dev_declared ^ set(fir.DEV_EXPORTS)
+    product = subprocess.run(["nm", "-D", "--defined-only", fir.LIB_PATH], capture_output=True, text=True).stdout
+    product_syms = {line.split()[-1] for line in product.splitlines() if line.strip()}
+    assert not [n for n in product_syms if "debug" in n or n in dev_declared], product_syms & dev_declared
+    assert {n for n in product_syms if n.startswith(("if_fir_", "if_bpf_"))} == declared
+    dev = fir.dev_lib()
+    for name in declared | dev_declared:
+        assert hasattr(dev, name), name
     # include/wb_detect.h lives in the same library
     import __graft_entry__ as g
     wb = g.load_pkg().wb_detect

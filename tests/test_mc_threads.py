@@ -28,6 +28,16 @@ def test_ranks_as_threads_match_single_channel_contexts(fake_rccl, world, channe
     assert "bit-identical" in run.stdout
 
 
+@pytest.mark.parametrize("d", [3, 4, 7])
+def test_ranks_as_threads_off_phase_chunks(fake_rccl, d):
+    """call lengths that leave the decimation phase != 0, chunked (215040-sample chunks, two slots of staging
+    per owned channel on the ranks other than 0): every channel bit-identical to an unchunked single-channel context."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mc_threads_check.py"), fake_rccl, "3", "4", "offphase%d" % d],
+                         capture_output=True, text=True, timeout=400)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert "bit-identical" in run.stdout
+
+
 def test_remote_filter_failure_reaches_the_root_and_nobody_hangs(fake_rccl):
     """Rank 1's filter is made to fail (test hook, IF_FIR_DEBUG) in the middle of a chunked call: the protocol completes
     on every rank, rank 1 reports its error, the root reports "rank 1 reported a filter failure" (status word), rank 2

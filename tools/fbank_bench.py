@@ -23,7 +23,7 @@ def main():
     taps = fir.bpf_design(taps_n, 0.0, 0.03)
     slots = [(2 * c + 1) % 16 for c in range(nch)]
     x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
-    with fir.IfFir(taps, 4, 0) as f:
+    with fir.IfFir(taps, 4, 0, dev=True) as f:
         m = f.out_count(n)
         outs = [torch.empty(2 * m, dtype=torch.float32, device="cuda") for _ in range(nch)]
         torch.cuda.synchronize()
@@ -51,7 +51,7 @@ def main():
     worst = 0.0
     ms_single = 0.0
     for c, s in enumerate(slots):
-        with fir.IfFir(taps, 4, 0) as f1:
+        with fir.IfFir(taps, 4, 0, dev=True) as f1:
             f1.set_nco(s / 16.0 if s <= 8 else s / 16.0 - 1.0)   # slots above 8 are negative frequencies
             f1.set_stream(stream.cuda_stream)
             f1.process_device(x.data_ptr(), ref.data_ptr(), n)

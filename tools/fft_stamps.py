@@ -19,7 +19,7 @@ n = 1 << log2n
 fir = g.load_pkg().if_fir
 torch.cuda.set_device(0)
 x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
-with fir.IfFir(fir.bpf_design(taps_n), decim, 0) as f:
+with fir.IfFir(fir.bpf_design(taps_n), decim, 0, dev=True) as f:
     f.set_backend(fir.BACKEND_HIP_FFT)
     f.set_tuning(variant)
     y = torch.empty(2 * f.out_count(n), dtype=torch.float32, device="cuda")

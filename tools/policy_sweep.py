@@ -25,7 +25,7 @@ def main():
                  (63, 8), (127, 8), (129, 8), (255, 8), (127, 16), (255, 16), (257, 16), (511, 16), (511, 32), (1023, 32),
                  (1023, 64), (255, 64), (2047, 1), (3073, 1), (3075, 1), (4095, 1), (4095, 4), (4095, 16)]:
         taps = (np.random.default_rng(t).standard_normal(t) / np.sqrt(t)).astype(np.float32)
-        with fir.IfFir(taps, d, 0) as f:
+        with fir.IfFir(taps, d, 0, dev=True) as f:
             if first:
                 f.synth_device(x.data_ptr(), 0, n, 0)
                 f.synchronize()

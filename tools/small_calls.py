@@ -7,7 +7,7 @@ taps=fir.bpf_design(255)
 for log2n in (16,18,20,22,24):
     n=1<<log2n
     x=torch.empty(2*n,dtype=torch.float32,device='cuda'); 
-    with fir.IfFir(taps,4,0) as f:
+    with fir.IfFir(taps,4,0, dev=True) as f:
         y=torch.empty(2*f.out_count(n),dtype=torch.float32,device='cuda')
         f.synth_device(x.data_ptr(),0,n,0); f.synchronize()
         for _ in range(20): f.process_device(x.data_ptr(),y.data_ptr(),n)

@@ -19,7 +19,7 @@ def main():
     torch.cuda.set_device(0)
     x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
     ref = None
-    with fir.IfFir(taps, decim, 0) as f:
+    with fir.IfFir(taps, decim, 0, dev=True) as f:
         m = f.out_count(n)
         y = torch.empty(2 * m, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
