@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "if_fir_kernels.h"
+#include "if_fir_fft_queue.h"
 
 namespace if_fir
 {
@@ -158,11 +159,11 @@ constexpr int XROW = 136;             // bytes per 16-entry row of the exchange 
 constexpr int XREG = 16 * XROW + 32;  // one 16x16 region (+32 so that the 4 regions start on different banks)
 constexpr int XBUF = 4 * XREG;        // per-wave exchange buffer
 constexpr int FFT_WAVES = 8;
+static_assert(FFT_WAVES == (int)QB, "one slot of a block group per wave of the workgroup");
 constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_TWD = 65536 + 2048, LDS_TWE = LDS_TWD + 8192,
               LDS_NCO = LDS_TWE + 8192, LDS_XB = LDS_NCO + 512;
 static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 constexpr int LDS_Q = LDS_XB + FFT_WAVES * XBUF; // workgroup block queue: slot counter (16 B) + ring of group entries
-constexpr int Q_RING = 16;
 constexpr int FFT_LDS_BYTES = LDS_Q + 16 + Q_RING * 8;
 
 __device__ __forceinline__ void exchange1_fwd(cf (&r)[64])
@@ -306,24 +307,55 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
     __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, IF_FIR_FFT_STORE_AUX);
 }
 
-// ---- block queue (two levels) -----------------------------------------------------------------------------------
-// Blocks are handed out in GROUPS of 8 consecutive blocks, one group at a time per workgroup, groups in global order:
-// at any moment the chip works on one compact window of the stream (DRAM pages and the overlap rows of neighbouring
-// blocks are shared by waves that run at the same time), and no wave holds work another one could do.
-//   * level 1, LDS: a wave takes the next SLOT of its workgroup (ds_add_rtn): slot s = block s % 8 of local group s / 8;
-//   * level 2, global: the wave that takes slot 0 of local group g fetches the global group of local group g + Q_AHEAD
-//     with one returning atomic (waited for on the spot: it sits where nothing else of this wave is in flight) and
-//     publishes it in an LDS ring; the first Q_AHEAD local groups are static (workgroup b: global groups b, wgs + b).
-// One global atomic per 8 blocks (a single address takes ~88 atomics/us; 70 k blocks in 0.5 ms would be 140/us), two
-// groups (16 slot takes = two block times, ~28 us) of slack before anybody needs its result.  (Q_AHEAD 1 measured the
-// same, 0.478 vs 0.474 ms interleaved: the waves of a launch finish over two block times either way, which is the
-// group granularity -- the last group a workgroup receives takes a block time to hand out and one to run --, not the
-// reserve.)  A ring entry is {local group, global group} in one 8-byte LDS word.
-constexpr unsigned Q_AHEAD = 2; // groups fetched ahead = static groups per workgroup
-__host__ __device__ __forceinline__ constexpr int64_t fft_static_group(int local_group, int64_t wg, int64_t wgs)
+// ---- block queue (two levels): if_fir_fft_queue.h, shared with the host simulation --------------------------------------
+// LDS image: slot counter at LDS_Q, ring of {local group, global group} words at LDS_Q + 16.
+struct DevQueue
 {
-    return (int64_t)local_group * wgs + wg;
+    char *smem;
+    unsigned int *gqueue; // this launch's global ticket counter
+    unsigned int *faultw; // third word of the queue block: bounded waits that expired (0 in a healthy launch)
+    int lane;
+    __device__ __forceinline__ unsigned long long *ring() const { return reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16); }
+    __device__ __forceinline__ unsigned slot_add()
+    {
+        unsigned s = 0;
+        if (lane == 0)
+            s = __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(smem + LDS_Q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(s);
+    }
+    __device__ __forceinline__ unsigned long long ring_load(unsigned i)
+    {
+        const unsigned long long e = __hip_atomic_load(&ring()[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)e), hi = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    }
+    __device__ __forceinline__ void ring_store(unsigned i, unsigned long long v)
+    {
+        if (lane == 0)
+            __hip_atomic_store(&ring()[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ unsigned ticket()
+    {
+        unsigned t = 0;
+        if (lane == 0)
+            t = atomicAdd(gqueue, 1u);
+        return __builtin_amdgcn_readfirstlane(t);
+    }
+    __device__ __forceinline__ void fault()
+    {
+        if (lane == 0)
+            atomicAdd(faultw, 1u);
+    }
+    __device__ __forceinline__ void pause() { __builtin_amdgcn_s_sleep(2); }
+    __device__ __forceinline__ unsigned wgs() const { return gridDim.x; }
+};
+// global group of local group g if its ring entry has been published already, else -1 (never waits)
+__device__ __forceinline__ int64_t queue_peek(DevQueue &q, unsigned g)
+{
+    const unsigned long long e = q.ring_load(g & (Q_RING - 1));
+    return (unsigned)e == g ? (int64_t)(unsigned)(e >> 32) : -1;
 }
+
 // (development, diag 8 / 128) touch one dword of every 128-byte line of [base + first, base + first + n8k * 8 KiB): the lines
 // land in L2 / the memory-side cache ahead of the row loads.  The destination is v255, which the kernel never allocates
 // (it uses ~212 VGPRs; the clobber raises the count to 256 = still two waves per SIMD), so the loads are fire-and-forget.
@@ -345,49 +377,6 @@ __device__ __forceinline__ void prefetch_span(const char *base, int64_t first, i
         const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)k * 8192u);
         asm volatile("buffer_load_dword v255, %0, %1, %2 offen" ::"v"(voff), "s"(srd), "s"(soff) : "v255");
     }
-}
-
-__device__ __forceinline__ int64_t queue_take(char *smem, unsigned int *gqueue, int lane, unsigned *local_group = nullptr)
-{
-    unsigned int *cnt = reinterpret_cast<unsigned int *>(smem + LDS_Q);
-    unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16);
-    unsigned s = 0;
-    if (lane == 0)
-        s = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    s = __builtin_amdgcn_readfirstlane(s);
-    const unsigned g = s >> 3, j = s & 7u;
-    if (j == 0)
-    {
-        unsigned t = 0;
-        if (lane == 0)
-            t = atomicAdd(gqueue, 1u);
-        t = __builtin_amdgcn_readfirstlane(t);
-        const unsigned long long e = ((unsigned long long)(Q_AHEAD * gridDim.x + t) << 32) | (unsigned long long)(g + Q_AHEAD);
-        if (lane == 0)
-            __hip_atomic_store(&ring[(g + Q_AHEAD) & (Q_RING - 1)], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    // the entry of group g was published by the taker of slot 0 of group g - Q_AHEAD (or at kernel start): it is almost
-    // always there already; its writer waits for nothing but its own global atomic, so this loop ends
-    unsigned long long e;
-    for (;;)
-    {
-        e = __hip_atomic_load(&ring[g & (Q_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((unsigned)e == g)
-            break;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    const unsigned gg = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
-    if (local_group)
-        *local_group = g;
-    return (int64_t)gg * 8 + j;
-}
-// global group of local group g if its ring entry has been published already, else -1 (never waits)
-__device__ __forceinline__ int64_t queue_peek(char *smem, unsigned g)
-{
-    const unsigned long long *ring = reinterpret_cast<const unsigned long long *>(smem + LDS_Q + 16);
-    const unsigned long long e = __hip_atomic_load(&ring[g & (Q_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)e), hi = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
-    return lo == g ? (int64_t)hi : -1;
 }
 
 // decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
@@ -468,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     int64_t blk = 0;
     if (plain_start)
     {
-        blk = fft_static_group(0, blockIdx.x, gridDim.x) * FFT_WAVES + wid;
+        blk = (int64_t)blockIdx.x * FFT_WAVES + wid; // slot wid of local group 0 = global group blockIdx.x
         // diag 4 (development, results stay correct): the second wave of every SIMD starts (diag >> 12) & 255 sleeps later
         if ((diag & 4) && wid >= FFT_WAVES / 2)
             for (int k = 0; k < ((diag >> 12) & 255); k++)
@@ -494,10 +483,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         // block queue: slot counter 0; the first local group(s) are static, the rest of the ring is empty
         if (threadIdx.x < Q_RING)
         {
-            unsigned long long e = ~0ull;
-            if (threadIdx.x < Q_AHEAD)
-                e = ((unsigned long long)fft_static_group(threadIdx.x, blockIdx.x, gridDim.x) << 32) | threadIdx.x;
-            reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16)[threadIdx.x] = e;
+            reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16)[threadIdx.x] = queue_ring_init(threadIdx.x, blockIdx.x, gridDim.x);
         }
         if (threadIdx.x == 0)
         {
@@ -509,7 +495,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         }
     }
     __syncthreads();
-    unsigned int *gqueue = queue + qsel;
+    DevQueue dq{smem, queue + qsel, queue + 2, lane};
+    if (plain_start && wid == 0)
+        queue_start(dq); // the fetch the (static) slot 0 of local group 0 owes
     // streaming state: the history of the NEXT call = the last HL samples of (history || input) (HL = the block overlap,
     // >= T-1: the first block of a call then sees the very samples an interior block sees), written to the other
     // ping-pong buffer by one wave (everything it reads is read-only in this launch); spares a launch per call
@@ -564,12 +552,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         st_r0 = __builtin_amdgcn_s_memrealtime();
         st_c0 = __builtin_amdgcn_s_memtime();
     }
-    // Work distribution: see queue_take()
+    // Work distribution: if_fir_fft_queue.h
     const int32_t waves_total = (int32_t)gridDim.x * FFT_WAVES;
     // diag 64 (development, results stay correct): waves 4-7 of every workgroup leave at once = one wave per SIMD
     // (occupancy experiment; the queue hands their share to the others)
     if (!plain_start)
-        blk = (diag & 32) ? 0 : ((diag & 64) && wid >= FFT_WAVES / 2) ? nblocks : queue_take(smem, gqueue, lane);
+        blk = (diag & 32) ? 0 : ((diag & 64) && wid >= FFT_WAVES / 2) ? nblocks : queue_take(dq);
     // diag 32 (development, results stay correct): static wave-interleaved blocks, no queue: block = it * waves + wave
     const bool static_map = (diag & 32) != 0;
     const int act_waves = (diag & 64) ? FFT_WAVES / 2 : FFT_WAVES;
@@ -685,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             // taken here: the block's own rows have all landed and the next block's are not issued yet, so the wait
             // behind the (rare) global atomic inside drains nothing
             unsigned lg = 0;
-            blk_next = queue_take(smem, gqueue, lane, &lg);
+            blk_next = queue_take(dq, &lg);
             // diag 8 / 128 (development, results stay correct): the lines of the NEXT local group are touched ahead of time,
             // 8: all 8 blocks by the wave that took slot 0 (one CU requests its 240 KB together), 128: block j by the taker of slot j
             if (diag & (8 | 128))
@@ -693,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 const unsigned jn = (unsigned)blk_next & 7u;
                 if ((diag & 128) || jn == 0)
                 {
-                    const int64_t gg1 = queue_peek(smem, lg + 1);
+                    const int64_t gg1 = queue_peek(dq, lg + 1);
                     const int64_t b0 = gg1 * 8 + ((diag & 128) ? (int64_t)jn : 0);
                     if (gg1 >= 0 && b0 < nblocks)
                     {
@@ -1026,7 +1014,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
         qsel = *a.queue_base & 1u;
     else
     {
-        hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);
+        hipError_t e = hipMemsetAsync(a.queue, 0, 8, a.stream);
         if (e != hipSuccess)
             return e;
     }

@@ -768,6 +768,17 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
 }
 
+// bounded waits of the block queue that expired (if_fir_fft_queue.h): third word of the queue block
+IF_FIR_API uint8_t if_fir_debug_queue_faults(if_fir_ctx_t *pCtx, uint32_t *pulFaults)
+{
+    if (!pCtx || !pulFaults)
+        return 0;
+    HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+    HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+    HIP_TRY(pCtx, hipMemcpy(pulFaults, static_cast<const char *>(pCtx->d_queue) + 8, 4, hipMemcpyDeviceToHost));
+    return 1;
+}
+
 // Host-only: the block-queue layout the overlap-save launcher would use for nblocks blocks on at most ulWorkgroups
 // workgroups; pllOut receives blocks per group, groups, static groups per workgroup, 0, ticket bound, workgroups.  The
 // CPU tests replay the queue under random interleavings and check that every block is handed out exactly once.

@@ -32,7 +32,7 @@ EXPORTS = [
 ]
 # every symbol include/if_fir_debug.h declares: exported by libif_fir_dev.so only
 DEV_EXPORTS = ["if_fir_time_device", "if_fir_debug_stamps", "if_fir_debug_fft_tables", "if_fir_debug_fft_schedule",
-               "if_fir_mc_debug_plan"]
+               "if_fir_mc_debug_plan", "if_fir_debug_queue_faults"]
 MC_ID_BYTES = 128
 
 
@@ -151,6 +151,8 @@ def _load(path, dev):
         L.if_fir_debug_fft_schedule.restype = u8
         L.if_fir_mc_debug_plan.argtypes = [u32, u32, u32, u64, u32, u32, u32, u64, u64, ctypes.POINTER(u64), u32]
         L.if_fir_mc_debug_plan.restype = u32
+        L.if_fir_debug_queue_faults.argtypes = [vp, ctypes.POINTER(u32)]
+        L.if_fir_debug_queue_faults.restype = u8
     _libs[path] = L
     return L
 
@@ -335,6 +337,12 @@ class IfFir:
         self._check(self._L.if_fir_time_device(self._ctx, ctypes.c_void_p(dev_in), ctypes.c_void_p(dev_out),
                                              int(samples), int(warmup), int(reps), ctypes.byref(ms)))
         return float(ms.value)
+
+    def debug_queue_faults(self):
+        """if_fir_debug_queue_faults() (development library): expired bounded waits of the block queue, 0 when healthy."""
+        n = ctypes.c_uint32(0)
+        self._check(self._L.if_fir_debug_queue_faults(self._ctx, ctypes.byref(n)))
+        return int(n.value)
 
     def debug_stamps(self, waves=None):
         """Arm (waves=None) or fetch the per-wave diagnostic stamps of the last persistent-kernel launch."""

@@ -294,6 +294,7 @@ def test_fft_backend_run_queue_on_small_grid(fir, oracle, t, d, i16):
         parts = [f.process(src[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
         l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
         assert l2 <= TOL and mx <= TOL, (l2, mx)
+        assert f.debug_queue_faults() == 0      # no bounded wait of the block queue expired
 
 
 def test_diagnostic_variants_need_the_debug_switch(fir, gpu_ok):

@@ -228,6 +228,23 @@ def test_overlap_save_block_queue_hands_out_every_block_once(fir):
             assert counter <= s["tickets"], (nblocks, wgs_max, counter, s)
 
 
+def test_block_queue_kernel_code_under_host_simulation():
+    """tests/c/fft_queue_sim.cpp compiles qo-100-tools_amd/csrc/if_fir_fft_queue.h -- the queue code the kernel runs -- for
+    the host and runs the waves of a launch as threads with random delays (also with the ticket fetches held back, the
+    interleaving ADVICE r2 describes): every block handed out exactly once, every wave leaves, no bounded wait expires,
+    the ticket counter stays below the launcher's bound."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(tempfile.mkdtemp(prefix="fft_queue_sim_"), "fft_queue_sim")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "qo-100-tools_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "c", "fft_queue_sim.cpp"), "-o", exe])
+    cases = [(1, 4, 0), (3, 4, 0), (8, 4, 0), (9, 4, 0), (17, 1, 0), (64, 8, 0), (65, 8, 1), (100, 3, 1), (1000, 6, 0),
+             (1000, 6, 1), (2049, 8, 0), (4369, 5, 1), (8191, 8, 1)]
+    for seed, (nblocks, wgs, delay) in enumerate(cases):
+        run = subprocess.run([exe, str(nblocks), str(wgs), str(seed + 1), str(delay)], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
+
+
 def test_no_overlap_save_instantiation_spills():
     """The build records the compiler's per-kernel resource remarks (csrc/if_fir_fft.resources.txt).  No instantiation of
     the overlap-save kernel may use scratch: a spill reload behind row loads in flight waits for all of them (vmcnt is
