@@ -201,6 +201,11 @@ def dry_run(args, rank, world, json_fd):
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t[0])
+    extra = {}
+    if args.scatter and use_dist:
+        extra["scatter_gather"] = dry_run_scatter(rank, world, decim)
+    if args.scatter_mc and use_dist:
+        extra["scatter_gather_mc"] = dry_run_scatter_mc(rank, world, taps_n, decim)
     if rank == 0:
         line = {"metric": "complex-IQ MSamples/s through %d-tap FIR" % taps_n,
                 "value": round(total_channels * n / (wall / args.steps) / 1e6, 3), "unit": "MSamples/s", "n_gpus": world,
@@ -210,10 +215,116 @@ def dry_run(args, rank, world, json_fd):
                 "config": {"workload": "DRY RUN of the launch path: a sleep stands for the filter (%s)" % desc,
                            "name": args.workload, "channels": total_channels, "channels_on_rank0": len(owned),
                            "parallelism": "channel c on rank c mod %d, no data-path collective" % world}}
+        if extra:
+            line["extra"] = extra
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dry_run_scatter(rank, world, decim):
+    """--dry-run --scatter: the control flow of the real --scatter leg (channel_shard.scatter_channels -> per-channel
+    filter -> gather_outputs, barriers in the same places) on CPU tensors over gloo; the filter is a stand-in that keeps
+    every decim-th sample, so rank 0 can check that every channel came back from the right owner in the right place."""
+    cs = graft.load_pkg().channel_shard
+    cpu = torch.device("cpu")
+    n = 1 << 12
+    m = (n + decim - 1) // decim
+    root_inputs = None
+    if rank == 0:
+        root_inputs = [torch.arange(2 * n, dtype=torch.float32) + 100000.0 * c for c in range(world)]
+    dist.barrier()
+    mine = cs.scatter_channels(root_inputs, world, n, cpu, root=0)
+    dist.barrier()
+    outs = {c: xin.view(-1, 2)[::decim].reshape(-1).clone() for c, xin in mine.items()}
+    dist.barrier()
+    res = cs.gather_outputs(outs, world, m, cpu, root=0)
+    dist.barrier()
+    ok = None
+    if rank == 0:
+        ok = all(torch.equal(res[c], root_inputs[c].view(-1, 2)[::decim].reshape(-1)) for c in range(world))
+    return {"dry_run": True, "channels": world, "ok": ok,
+            "note": "channel_shard scatter -> stand-in filter -> gather over gloo (CPU rehearsal of the --scatter leg)"}
+
+
+def dry_run_scatter_mc(rank, world, taps_n, decim):
+    """--dry-run --scatter-mc: the transfer plan the C front executes (if_fir_mc_debug_plan: chunks, groups, posting
+    order) run by REAL processes over gloo: every group is one batch of point-to-point operations, an owner "filters" a
+    chunk (stand-in: keeps the samples on the decimation grid) between its scatter and its gather, chunk k lives in slot
+    k & 1 of the owners' staging as in if_fir_mc.cpp.  Rank 0 checks every remote channel's output bytes and the status
+    words.  An off-phase stream position and three chunks are used on purpose."""
+    fir = graft.load_pkg().if_fir
+    unit = fir.MC_CHUNK_UNIT
+    consumed, samples, channels = 3, 2 * unit + 1001, world + 1
+    plan = fir.mc_debug_plan(world, channels, rank, samples, 8, decim, consumed, unit, taps=taps_n)
+    n0 = (decim - consumed % decim) % decim
+    m_total = (samples - n0 + decim - 1) // decim if samples > n0 else 0
+    root = rank == 0
+
+    def pattern(c):   # int64 sample ids as the 8-byte "samples" of channel c
+        return torch.arange(samples, dtype=torch.int64) + (c << 40)
+
+    ins = {c: pattern(c) for c in range(channels)} if root else {}
+    outs = {c: torch.zeros(m_total, dtype=torch.int64) for c in range(channels)} if root else {}
+    slot_in = max([o["bytes"] // 8 for o in plan if o["phase"] == 0] + [1])
+    slot_out = max([o["bytes"] // 8 for o in plan if o["phase"] == 1] + [1])
+    owned = [c for c in range(channels) if c % world == rank]
+    st_in = {c: torch.zeros(2 * slot_in, dtype=torch.int64) for c in owned} if not root else {}
+    st_out = {c: torch.zeros(2 * slot_out, dtype=torch.int64) for c in owned} if not root else {}
+    status = torch.zeros(1 + world, dtype=torch.int32)
+    chunk_first = {}   # chunk -> first input sample (from the scatter offsets this rank sees)
+    groups = {}
+    for o in plan:
+        groups.setdefault(o["group"], []).append(o)
+    last_group = max([o["group"] for o in plan] + [-1])
+    # every rank walks the same group numbers (a rank without operations in a group skips it)
+    gmax = torch.tensor([last_group], dtype=torch.int64)
+    dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+    for g in range(int(gmax.item()) + 1):
+        ops, after = [], []
+        for o in groups.get(g, []):
+            k, c, cnt = o["chunk"], o["channel"], o["bytes"] // 8
+            if o["phase"] == 2:
+                buf = status[(o["offset"] // 4):(o["offset"] // 4) + 1]
+            elif o["phase"] == 0:
+                first = o["offset"] // 8
+                buf = ins[c][first:first + cnt] if root else st_in[c][(k & 1) * slot_in:(k & 1) * slot_in + cnt]
+                if not root:
+                    after.append((c, k, first, cnt))
+            else:
+                first = o["offset"] // 8
+                buf = outs[c][first:first + cnt] if root else st_out[c][(k & 1) * slot_out:(k & 1) * slot_out + cnt]
+            ops.append(dist.P2POp(dist.isend if o["kind"] == 0 else dist.irecv, buf, o["peer"]))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for c, k, first, cnt in after:   # the owner's stand-in filter of chunk k: samples on the decimation grid
+            x = st_in[c][(k & 1) * slot_in:(k & 1) * slot_in + cnt]
+            skip = (decim - (consumed + first) % decim) % decim
+            y = x[skip::decim]
+            st_out[c][(k & 1) * slot_out:(k & 1) * slot_out + y.numel()] = y
+    dist.barrier()
+    ok = None
+    if root:
+        ok = True
+        for c in range(channels):
+            if c % world == 0:
+                continue
+            ok = ok and bool(torch.equal(outs[c], pattern(c)[n0::decim]))
+        ok = ok and bool((status == 0).all())
+    return {"dry_run": True, "world": world, "channels": channels, "chunks": len({o["chunk"] for o in plan if o["phase"] == 0}),
+            "groups": int(gmax.item()) + 1, "ok": ok,
+            "note": "if_fir_mc_debug_plan executed group by group over gloo with two-slot staging and a stand-in filter"}
+
+
+def committed_traffic(workload, backend_name):
+    """profiles/traffic.json record of a workload's kernel (TCC counters of committed rocprofv3 passes), or None."""
+    try:
+        key = workload + (":fir_fft" if backend_name == "hip_fft" else ":fir_direct")
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+    except Exception:   # noqa: BLE001
+        return None
 
 
 def time_config(fir, name, backend, x, dev, stream, steps, warmup, names):
@@ -365,6 +476,21 @@ def main():
         for fc, xc, yc in more:
             fc.process_device(xc.data_ptr(), yc.data_ptr(), n)
 
+    # ---- the COLD figure: the driver's own W warm-up + K steps right away, before any conditioning ------
+    # Reported beside `value` (roofline.cold_*), never as `value`: what a caller sees who starts filtering on an idle chip.
+    cold_ms = None
+    if args.condition_ms > 0:
+        for _ in range(args.warmup):
+            step_stream()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        for _ in range(args.steps):
+            step_stream()
+        c1.record(stream)
+        torch.cuda.synchronize()
+        cold_ms = c0.elapsed_time(c1) / args.steps
+    cold_passes = (args.warmup + args.steps) if cold_ms is not None else 0
+
     # ---- device conditioning and the comparison measurements, BEFORE the headline ---------------------------------
     # After idling, the chip's power management first boosts, then clamps the clock hard for ~20 launches (10 ms) and
     # only then settles (profiles/r02a_kernel_trace_summary.json: 0.48-0.52 ms, then 0.60-0.67 ms, then 0.49 ms per
@@ -450,6 +576,13 @@ def main():
                 cfgs[cname] = {"workload": WORKLOADS[cname][3]}
                 for label, b, st, wu in forms:
                     cfgs[cname][label] = time_config(fir, cname, b, x, dev, stream, st, wu, names)
+                # HBM bytes per launch of this config's AUTO kernel from the committed counter passes (another box)
+                rec = committed_traffic(cname, cfgs[cname]["auto"]["backend"])
+                if rec:
+                    cfgs[cname]["auto"]["traffic"] = rec.get("hbm_bytes_per_launch")
+                    cfgs[cname]["auto"]["traffic_over_algorithmic"] = round(
+                        rec.get("hbm_bytes_per_launch") / (algorithmic_bytes_per_sample(WORKLOADS[cname][1]) * (1 << WORKLOADS[cname][2])), 4)
+                    cfgs[cname]["auto"]["traffic_source"] = "profiles/traffic.json (%s, rocprofv3 FETCH_SIZE/WRITE_SIZE passes)" % rec.get("round")
         except Exception as e:   # noqa: BLE001 - context only, never fatal
             cfgs["error"] = repr(e)
         extra["configs"] = cfgs
@@ -481,15 +614,15 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
     per_step = [a.elapsed_time(b) for a, b in zip([ev0] + step_ev[:-1], step_ev)]   # this rank's steps, HIP events
-    t = torch.tensor([wall, dev_ms_per_step], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall, dev_ms_per_step, cold_ms if cold_ms is not None else 0.0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max, dev_ms_max = float(t[0].item()), float(t[1].item())
+    wall_max, dev_ms_max, cold_ms_max = float(t[0].item()), float(t[1].item()), float(t[2].item())
 
     # whole-output check of the TIMED context's last step against a different kernel family in the same stream state
     # (a work-distribution bug that leaves blocks unwritten makes a launch look fast; windows do not see it)
-    whole = whole_output_check(fir, f, taps, decim, x, y, n, i16, stream, local_rank, cond_passes + args.warmup + args.steps, names,
-                               nco)
+    whole = whole_output_check(fir, f, taps, decim, x, y, n, i16, stream, local_rank,
+                               cold_passes + cond_passes + args.warmup + args.steps, names, nco)
     if use_dist:
         okt = torch.tensor([1.0 if whole["ok"] else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
@@ -621,6 +754,7 @@ def main():
             "metric": "complex-IQ MSamples/s through %d-tap FIR" % taps_n,
             "value": round(value, 1), "unit": "MSamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "cold_ms_per_step": round(cold_ms_max, 4) if cold_ms is not None else None,
             "higher_is_better": True, "scaling": "strong" if args.channels else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "taps": taps_n, "decimation": decim,
                        "samples_per_channel": n, "channels": total_channels, "channels_on_rank0": len(owned),
@@ -634,6 +768,11 @@ def main():
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "kernel_ms": round(dev_ms_max, 4),
+                         "cold_kernel_ms": round(cold_ms_max, 4) if cold_ms is not None else None,
+                         "cold_frac": round(bytes_per_launch / (cold_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if cold_ms is not None else None,
+                         "cold_note": "the same W warm-up + K steps timed BEFORE any conditioning (chip coming from idle: its "
+                                      "power management clamps the clock for the first ~20 launches); `value` and `frac` are "
+                                      "the settled rate of a filter in continuous service",
                          "kernel_ms_median": round(float(np.median(per_step)), 4),
                          "kernel_ms_min": round(float(np.min(per_step)), 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,

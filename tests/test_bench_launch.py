@@ -49,3 +49,16 @@ def test_single_gpu_dry_run_and_failing_child_exit_code():
     # a child that fails (fewer channels than GPUs) must surface as a non-zero exit code and no JSON line
     p = run_bench("--gpus", "2", "--channels", "1", "--dry-run")
     assert p.returncode != 0 and not p.stdout.strip()
+
+
+def test_scatter_legs_are_rehearsed_over_gloo():
+    """VERDICT r2 #6a: `--scatter` (channel_shard) and `--scatter-mc` (the C front's transfer plan: chunks, groups, two-slot
+    staging) run their control flow with real processes over gloo in --dry-run, so the first 8-GPU run is not the first
+    execution; rank 0 checks that every channel's bytes came back in place."""
+    for gpus in ("2", "3"):
+        p = run_bench("--gpus", gpus, "--dry-run", "--steps", "2", "--warmup", "0", "--scatter", "--scatter-mc")
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+        sg, mc = line["extra"]["scatter_gather"], line["extra"]["scatter_gather_mc"]
+        assert sg["ok"] is True and sg["channels"] == int(gpus)
+        assert mc["ok"] is True and mc["chunks"] == 3 and mc["channels"] == int(gpus) + 1 and mc["groups"] == 7
