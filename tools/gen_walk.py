@@ -32,7 +32,7 @@ SGPR_RING_BASE = 36      # s[36:99]: 4 blocks x 16 taps
 SGPR_RING_BLOCKS = 4
 
 
-def gen_walk(T, D, R, SEG, Q, U):
+def gen_walk(T, D, R, SEG, Q, U, W=1):
     """Returns (function name, asm lines, clobber list, n_tot)."""
     assert T % 2 == 1 and U in (1, 2)
     DR = D * R
@@ -48,7 +48,7 @@ def gen_walk(T, D, R, SEG, Q, U):
         return (u // DR) * CH + (u % DR) * 8
 
     # ---- register map ---------------------------------------------------------------------------------------
-    ring_slots = Q + 2
+    ring_slots = Q + W + 1                       # longest lead of a read over its use is Q + W units
     need = 2 * R + 2 * U * ring_slots
     acc_base = (256 - need) & ~3                 # temporaries sit at the top of the arch VGPR file
     ring_base = acc_base + 2 * R                 # slot i = v[ring_base + 2*U*i ...]
@@ -100,11 +100,19 @@ def gen_walk(T, D, R, SEG, Q, U):
         drain_at.add(first_use[b])
 
     # ---- LDS read issue schedule ---------------------------------------------------------------------------
+    # A tap block is only trusted after an lgkmcnt(0), which also waits for every LDS read in flight.  No LDS read is
+    # issued in the W steps ahead of a drain (round 3; W = 1 is round 1's "one step early"): whatever would fall there is
+    # issued just before that window, so the drain finds the youngest read at least W steps old.
     issue_step = {}
     for ui in range(nunits):
         s = ui - Q
-        if s + 1 in drain_at:
-            s -= 1                               # would be the youngest read at the drain: issue it a step earlier
+        moved = True
+        while moved:
+            moved = False
+            for d in drain_at:
+                if d - W <= s <= d - 1:
+                    s = d - W - 1
+                    moved = True
         issue_step[ui] = s
     reads_at = {}
     for ui, s in issue_step.items():
@@ -174,15 +182,16 @@ def gen_walk(T, D, R, SEG, Q, U):
     name = "walk_asm_T%d_D%d_R%d_S%d" % (T, D, R, SEG)
     clobbers = ["v%d" % i for i in range(acc_base, vtop)]
     clobbers += ["s%d" % i for i in range(SGPR_RING_BASE, SGPR_RING_BASE + 16 * SGPR_RING_BLOCKS)]
-    return name, lines, clobbers, dict(T=T, D=D, R=R, SEG=SEG, Q=Q, U=U, fma=n_fma, reads=len(issued),
+    return name, lines, clobbers, dict(T=T, D=D, R=R, SEG=SEG, Q=Q, U=U, W=W, fma=n_fma, reads=len(issued),
                                        drains=len(drain_at), vgpr_top=vtop)
 
 
 def emit_function(f, name, lines, clobbers, meta, suffix=""):
     R = meta["R"]
-    f.write("// %s%s: T=%d D=%d R=%d SEG=%d  prefetch Q=%d units of %d sample(s); %d v_pk_fma_f32, %d LDS reads, "
-            "%d mid-walk tap drains\n" % (name, suffix, meta["T"], meta["D"], R, meta["SEG"], meta["Q"], meta["U"],
-                                          meta["fma"], meta["reads"], meta["drains"]))
+    f.write("// %s%s: T=%d D=%d R=%d SEG=%d  prefetch Q=%d units of %d sample(s), no LDS read in the %d step(s) ahead of a "
+            "tap drain; %d v_pk_fma_f32, %d LDS reads, %d mid-walk tap drains\n" %
+            (name, suffix, meta["T"], meta["D"], R, meta["SEG"], meta["Q"], meta["U"], meta["W"], meta["fma"], meta["reads"],
+             meta["drains"]))
     f.write("__device__ __forceinline__ void %s%s(unsigned lds_lane_addr, const float *taps, f2 (&tot)[%d])\n{\n"
             % (name, suffix, R))
     f.write("    asm volatile(\n")
@@ -198,7 +207,7 @@ CONFIGS = [
     # (T, D, R, SEG, [(suffix, Q, U), ...])
     # only what the library launches: the decimating walks (the D = 1 wave-kernel walks of round 1 were reachable through
     # tuning variants only -- the D = 1 configurations run the compiler-scheduled workgroup kernel -- and were removed)
-    (255, 4, 8, 32, [("", 4, 1), ("_b128", 2, 2)]),
+    (255, 4, 8, 32, [("", 4, 1), ("_b128", 2, 2), ("_b128_w2", 3, 2, 2), ("_b128_w3", 3, 2, 3), ("_b128_q4w2", 4, 2, 2)]),
     (127, 4, 8, 32, [("", 4, 1)]),
 ]
 
@@ -213,8 +222,10 @@ def main():
         f.write("// Hand-scheduled gfx950 assembly of the direct-form FIR walk (see the generator's docstring).\n")
         f.write("#pragma once\n\nnamespace if_fir\n{\n\n")
         for (T, D, R, SEG, variants) in CONFIGS:
-            for (suffix, Q, U) in variants:
-                name, lines, clobbers, meta = gen_walk(T, D, R, SEG, Q, U)
+            for variant in variants:
+                suffix, Q, U = variant[:3]
+                W = variant[3] if len(variant) > 3 else 1
+                name, lines, clobbers, meta = gen_walk(T, D, R, SEG, Q, U, W)
                 emit_function(f, name, lines, clobbers, meta, suffix)
         f.write("} // namespace if_fir\n")
     print("wrote", os.path.normpath(args.out))
