@@ -379,22 +379,14 @@ __device__ __forceinline__ void prefetch_span(const char *base, int64_t first, i
     }
 }
 
-// decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
-// (4 x 16 x 16, tools/fft_model.py inverse_dec4) produces y[4m'] directly: lane = 4*mu1+mu2, slot mu0 -> y_D[64*mu0+lane]
-__device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], const f2v *twd, const f2v *twe, char *xb,
-                                             int lane)
+// common tail of the small inverses: a[j], j = 4 i + low (low = mu2 of the 1024-point inverse, or the channel-in-batch of the
+// 16-slot bank), k0 = 4 g + i, k1 = lane % 16:
+//   X: row transposition (one round of exchange 2): element j of lane (g, k1) -> lane (g, j), slot k1; iFFT16 over k1 -> mu1
+//   twiddle conj W256^(k0 mu1);  Y: element mu1 of lane (k0, low) -> lane 4 mu1 + low, slot k0;  iFFT16 over k0 -> mu0
+// result: lane = 4 mu1 + low, slot mu0
+__device__ __forceinline__ void inverse_tail256(cf (&a)[16], cf (&c)[16], const f2v *twe, char *xb, int lane)
 {
     const int g = lane >> 4, m = lane & 15;
-    cf a[16];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-    {
-        bfly4<true>(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3], a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
-#pragma unroll
-        for (int mu2 = 1; mu2 < 4; mu2++)
-            a[4 * i + mu2] = cmul_v<true>(a[4 * i + mu2], twd[(i * 4 + mu2) * 64 + lane]);
-    }
-    // X: row transposition (one round of exchange 2): element j of lane (g, k1) -> lane (g, j), slot k1
     {
         char *wr = xb + g * XREG + m * 8;
         const char *rd = xb + g * XREG + m * XROW;
@@ -409,10 +401,9 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
 #pragma unroll
     for (int mu1 = 1; mu1 < 16; mu1++)
         a[mu1] = cmul_v<true>(a[mu1], twe[mu1 * 64 + lane]);
-    // Y: among the 16 lanes that share mu2: element mu1 of lane (k0, mu2) -> lane 4*mu1 + mu2, slot k0
     {
-        const int k0 = 4 * g + (m >> 2), mu2 = m & 3;
-        char *wr = xb + mu2 * XREG + k0 * 8;                       // + mu1*XROW : element (mu1, k0) of region mu2
+        const int k0 = 4 * g + (m >> 2), low = m & 3;
+        char *wr = xb + low * XREG + k0 * 8;                          // + mu1*XROW : element (mu1, k0) of region `low`
         const char *rd = xb + (lane & 3) * XREG + (lane >> 2) * XROW; // + k0*8
 #pragma unroll
         for (int j = 0; j < 16; j++)
@@ -424,7 +415,24 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
     fft16<true>(c); // over k0 -> mu0
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN, bool DECN, bool ACC>
+// decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
+// (4 x 16 x 16, tools/fft_model.py inverse_dec4) produces y[4m'] directly: lane = 4*mu1+mu2, slot mu0 -> y_D[64*mu0+lane]
+__device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], const f2v *twd, const f2v *twe, char *xb,
+                                             int lane)
+{
+    cf a[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        bfly4<true>(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3], a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+#pragma unroll
+        for (int mu2 = 1; mu2 < 4; mu2++)
+            a[4 * i + mu2] = cmul_v<true>(a[4 * i + mu2], twd[(i * 4 + mu2) * 64 + lane]);
+    }
+    inverse_tail256(a, c, twe, xb, lane);
+}
+
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, int CHAN, bool DECN, bool ACC>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int HL, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
@@ -437,13 +445,13 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // samples with the second partition's table and adds its result to what the first launch stored
     static_assert(!ACC || (!DEC4 && !CHAN && OVL_ROWS == 32), "accumulating store: full-rate pipeline, 32 overlap rows");
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
-    static_assert(!CHAN || (DEC4 && !NCO), "the channelizer is a decimate-by-4 variant");
+    static_assert(CHAN == 0 || ((CHAN == 4 || CHAN == 16) && DEC4 && !NCO), "the filter bank is a decimating variant (4 or 16)");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
     const char *in = reinterpret_cast<const char *>(in_);
     constexpr int L = FFT_N - OVL;         // new input samples per block
-    constexpr int LOUT = DEC4 ? L / 4 : L; // outputs per block
+    constexpr int LOUT = CHAN == 16 ? L / 16 : DEC4 ? L / 4 : L; // outputs per block (per channel)
     constexpr int EARLY_GROUPS = IF_FIR_FFT_EARLY_GROUPS; // dec4: batches of next-block loads issued during pass 3
     constexpr int LAUX = IF_FIR_FFT_LOAD_AUX(OVL_ROWS); // cache policy of the row loads
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -700,7 +708,79 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         // outputs beyond M are dropped by the descriptor's bounds check
         const int64_t obase = blk * LOUT;
         const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
-        if constexpr (CHAN)
+        if constexpr (CHAN == 16)
+        {
+            // ---- 16-slot filter bank at the channel rate (decimation 16, round 3; tools/fft_model.py bank16) --------------
+            // Channel s = the prototype moved up by s/16 cycles/sample; decimating by 16 aliases every slot centre to DC.
+            // Folded spectrum of ALL 16 slots from one 16-point transform per group:
+            //   Z_s(k0, k1) = sum_k2 H((k2 - s) mod 16) Y(k2) = FFT16(t * G0)[s],  G0[n2] = sum_k2 H(k2) W16^(n2 k2) (host table)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                cf t[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    t[j] = cmul_v<false>(r[phys(i, j)], hp[(i * 16 + j) * 64 + lane]);
+                fft16<false>(t);
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    r[phys(i, j)] = t[j]; // slot (i, s = j)
+            }
+            // 256-point inverses, four slots at a time (cs = slot % 4 takes the place of mu2 in the 1024-point inverse):
+            // lane = 4 mu1 + cs, slot mu0 -> y_s[16 mu0 + mu1], s = 4 b + cs; each lane stores to ITS channel's buffer
+            constexpr int MU0_FIRST = OVL_ROWS / 4;
+            const int cs = lane & 3, mu1 = lane >> 2;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+            {
+                cf a[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        a[4 * i + q] = r[phys(i, 4 * b + q)];
+                // these 16 registers are dead: refill them with rows of the next block (the last batch after its inverse,
+                // to keep the temporaries out of scratch)
+                if (b < EARLY_GROUPS && next_fast)
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, 4 * b + q));
+                }
+                cf c[16];
+                inverse_tail256(a, c, twe, xb, lane);
+                if (b >= EARLY_GROUPS && next_fast)
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, 4 * b + q));
+                }
+                // this lane's channel: buffer and call-constant mix-down phase exp(-j 2 pi s (abs0 + n0) / 16)
+                float2 *po = cs == 0 ? chan.out[4 * b] : cs == 1 ? chan.out[4 * b + 1] : cs == 2 ? chan.out[4 * b + 2] : chan.out[4 * b + 3];
+                const cf w0 = {chan.rot0[4 * b][0], chan.rot0[4 * b][1]}, w1 = {chan.rot0[4 * b + 1][0], chan.rot0[4 * b + 1][1]},
+                         w2 = {chan.rot0[4 * b + 2][0], chan.rot0[4 * b + 2][1]}, w3 = {chan.rot0[4 * b + 3][0], chan.rot0[4 * b + 3][1]};
+                const cf wl = cs == 0 ? w0 : cs == 1 ? w1 : cs == 2 ? w2 : w3;
+                const int64_t o0 = obase + mu1;
+                if (po != nullptr && !(diag & 2))
+                {
+#pragma unroll
+                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    {
+                        const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
+                        if (idx < M)
+                        {
+                            const cf v = cmul_v<false>(c[mu0], wl);
+                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                        }
+                    }
+                }
+            }
+        }
+        else if constexpr (CHAN == 4)
         {
             // ---- uniform filter bank: one forward transform, one decimated inverse per channel ---------
             // Channel slot s = the prototype moved to s/16 cycles/sample and mixed down: H_s(k2) = H(k2 - s), so with the
@@ -983,12 +1063,12 @@ void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s)
     s.tickets = groups + 2 * s.wgs; // upper bound of the counter at the end of the launch
 }
 
-template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, bool CHAN = false, bool DECN = false, bool ACC = false>
+template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, int CHAN = 0, bool DECN = false, bool ACC = false>
 static hipError_t launch_fft_t(const LaunchArgs &a)
 {
     auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN, ACC>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
-    constexpr int LOUT = DEC4 ? L / 4 : L;
+    constexpr int LOUT = CHAN == 16 ? L / 16 : DEC4 ? L / 4 : L;
     static DeviceSetup setup;
     int ncus = 0;
     {
@@ -1064,9 +1144,11 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
 {
     if (a.chan)
     {
-        if (a.D != 4 || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
+        if ((a.D != 4 && a.D != 16) || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
             return hipErrorInvalidConfiguration;
-        return a.in_i16 ? launch_fft_t<ROWS, true, true, false, true>(a) : launch_fft_t<ROWS, true, false, false, true>(a);
+        if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
+            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 16>(a) : launch_fft_t<ROWS, true, false, false, 16>(a);
+        return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 4>(a) : launch_fft_t<ROWS, true, false, false, 4>(a);
     }
     const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
     if (a.D == 4)
@@ -1170,7 +1252,7 @@ hipError_t launch_fft(const LaunchArgs &a)
 //   [64 KB, 66 KB)  tw2[k1*16 + n2]            = W256^(n2*k1)
 //   [66 KB, 82 KB)  twd, twe: twiddles of the decimate-by-4 1024-point inverse
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale,
-                      float *tables /* FFT_TABLE_FLOATS floats */)
+                      float *tables /* FFT_TABLE_FLOATS floats */, int bank)
 {
     const double PI2 = 6.283185307179586476925286766559;
     float *tw1 = tables, *hp = tables + 2 * 4096, *tw2 = tables + 4 * 4096;
@@ -1242,6 +1324,27 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                 hd[2 * ((i * 16 + k2) * 64 + lane) + 0] = re / 4096.0 * in_scale; // in_scale: 2^-15 for raw int16 samples
                 hd[2 * ((i * 16 + k2) * 64 + lane) + 1] = im / 4096.0 * in_scale;
             }
+    if (bank == 16)
+    {
+        // 16-slot filter bank at the channel rate: G0[n2] = sum_k2 H(k0 + 16 k1 + 256 k2) W16^(n2 k2) at ((i*16 + n2)*64 + lane)
+        // (pass 3, the multiplication by the slot's H and the 16-way alias fold merged; see the kernel, CHAN == 16)
+        for (int i = 0; i < 4; i++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int n2 = 0; n2 < 16; n2++)
+                {
+                    double re = 0.0, im = 0.0;
+                    for (int k2 = 0; k2 < 16; k2++)
+                    {
+                        const double *h = &hd[2 * ((i * 16 + k2) * 64 + lane)];
+                        const int e = (256 * n2 * k2) & 4095;
+                        re += h[0] * ct[e] - h[1] * st[e];
+                        im += h[0] * st[e] + h[1] * ct[e];
+                    }
+                    hp[2 * ((i * 16 + n2) * 64 + lane) + 0] = (float)re;
+                    hp[2 * ((i * 16 + n2) * 64 + lane) + 1] = (float)im;
+                }
+        return;
+    }
     if (D != 4)
     {
         for (int e = 0; e < 2 * 4096; e++)

@@ -58,7 +58,8 @@ struct LaunchArgs
                           // itself; nullptr = the caller runs launch_history (all other backends, or no outputs)
     uint32_t *queue_base; // host: which of the two counters in `queue` the next overlap-save launch draws from (each
     bool *queue_valid;    //       launch zeroes the other one); *queue_valid = false after anybody else touched them
-    const ChanArgs *chan; // filter-bank launch (overlap-save backend, D = 4): `out` is unused, outputs go to chan->out[]
+    const ChanArgs *chan; // filter-bank launch (overlap-save backend, D = 4 or 16): `out` is unused, outputs go to chan->out[]
+                          // (D = 16: all 16 slots are computed; out[] and rot0[] are indexed by SLOT, nullptr = not wanted)
 };
 
 // output m of a call is rotated by exp(+j*2*pi*phi/2^32), phi = nco_phi0 + m * nco_delta (mod 2^32):
@@ -121,7 +122,9 @@ struct FftSchedule
 };
 void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s); // host-only: run-queue layout of a launch
 hipError_t launch_fft(const LaunchArgs &a);
-void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale, float *tables);
+// bank = 16: the table of the 16-slot filter bank at the channel rate (decimation 16) in place of H
+void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale, float *tables,
+                      int bank = 0);
 
 int fft_overlap_rows(int T);
 // history buffers hold the last `hist_len` samples of the stream (>= T-1; hist_in/hist_out: whole buffers)

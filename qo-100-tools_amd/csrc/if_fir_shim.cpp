@@ -47,6 +47,7 @@ struct if_fir_ctx
     uint32_t nco_word; // SPEC §3.2 phase word (0 = no NCO)
     float *h_eff; // NCO on: effective complex taps g[k] = h[k] e^{+j theta k} (2T floats), else nullptr
     void *d_fft_tables; // overlap-save backend tables (built on first use)
+    void *d_fft_tables_bank; // 16-slot filter bank (decimation 16): its own table image (built on first use)
     void *d_queue; // atomic run queue of the persistent kernels
     uint32_t queue_base; // overlap-save launches alternate between two counters: the one the next launch draws from ...
     bool queue_valid;    // ... valid while nobody else (direct kernel, memset) touched the queue words
@@ -175,6 +176,35 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
     if (e != hipSuccess)
     {
         set_err(ctx, "overlap-save tables: upload failed: %s", hipGetErrorString(e));
+        return 0;
+    }
+    return 1;
+}
+
+// table image of the 16-slot filter bank at the channel rate (decimation-16 contexts, real taps, no NCO)
+static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
+{
+    if (ctx->d_fft_tables_bank)
+        return 1;
+    float *tab = (float *)malloc(sizeof(float) * if_fir::FFT_TABLE_FLOATS);
+    if (!tab)
+    {
+        set_err(ctx, "filter-bank tables: out of host memory");
+        return 0;
+    }
+    if_fir::fft_build_tables(ctx->h_taps, ctx->T, 0, ctx->D, 0u, ctx->in_i16 ? 0x1p-15 : 1.0, tab, 16);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess)
+        e = hipMalloc(&ctx->d_fft_tables_bank, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
+    if (e == hipSuccess)
+        e = hipMemcpy(ctx->d_fft_tables_bank, tab, sizeof(float) * if_fir::FFT_TABLE_FLOATS, hipMemcpyHostToDevice);
+    free(tab);
+    if (e != hipSuccess)
+    {
+        if (ctx->d_fft_tables_bank)
+            (void)hipFree(ctx->d_fft_tables_bank);
+        ctx->d_fft_tables_bank = nullptr;
+        set_err(ctx, "filter-bank tables: upload failed: %s", hipGetErrorString(e));
         return 0;
     }
     return 1;
@@ -350,6 +380,8 @@ IF_FIR_API void if_fir_destroy(if_fir_ctx_t *pCtx)
         (void)hipFree(pCtx->d_queue);
     if (pCtx->d_fft_tables)
         (void)hipFree(pCtx->d_fft_tables);
+    if (pCtx->d_fft_tables_bank)
+        (void)hipFree(pCtx->d_fft_tables_bank);
     free(pCtx->h_taps);
     free(pCtx->h_eff);
     delete pCtx;
@@ -544,13 +576,18 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     if (chan)
     {
         // mix-down phase of every channel at this call's first output: exp(-j 2 pi slot (consumed + n0) / 16)
-        for (uint32_t c = 0; c < chan->count; c++)
+        // (decimation 16: the arrays are indexed by slot, all 16 are filled)
+        const uint32_t entries = ctx->D == 16 ? 16u : chan->count;
+        for (uint32_t c = 0; c < entries; c++)
         {
-            const uint32_t e = (uint32_t)((chan->slot[c] * ((ctx->consumed + n0) & 15u)) & 15u);
+            const uint32_t slot = ctx->D == 16 ? c : chan->slot[c];
+            const uint32_t e = (uint32_t)((slot * ((ctx->consumed + n0) & 15u)) & 15u);
             chan->rot0[c][0] = (float)cos(-2.0 * M_PI * (double)e / 16.0);
             chan->rot0[c][1] = (float)sin(-2.0 * M_PI * (double)e / 16.0);
         }
         a.chan = chan;
+        if (ctx->D == 16)
+            a.fft_tables = ctx->d_fft_tables_bank;
     }
     a.queue_base = &ctx->queue_base;
     a.queue_valid = &ctx->queue_valid;
@@ -604,10 +641,10 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
         set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot and output arrays", if_fir::CHAN_MAX);
         return 0;
     }
-    if (pCtx->D != 4 || pCtx->ctaps || pCtx->nco_word || !if_fir::fft_supported(pCtx->T, pCtx->D) ||
+    if ((pCtx->D != 4 && pCtx->D != 16) || pCtx->ctaps || pCtx->nco_word || !if_fir::fft_supported(pCtx->T, pCtx->D) ||
         if_fir::fft_two_partitions(pCtx->T))
     {
-        set_err(pCtx, "if_fir_channelizer_process_device: needs real taps (<= 3073), decimation 4, no NCO");
+        set_err(pCtx, "if_fir_channelizer_process_device: needs real taps (<= 3073), decimation 4 or 16, no NCO");
         return 0;
     }
     if (pCtx->backend != IF_FIR_BACKEND_HIP_FFT)
@@ -626,6 +663,19 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
                           "aligned device pointer", c);
             return 0;
         }
+        if (pCtx->D == 16)
+        {
+            // channel rate: the kernel computes all 16 slots from one forward transform and stores the wanted ones;
+            // its arrays are indexed by slot
+            if (chan.out[pulSlots[c]])
+            {
+                set_err(pCtx, "if_fir_channelizer_process_device: slot %u is listed twice (decimation 16 takes each slot once)",
+                        pulSlots[c]);
+                return 0;
+            }
+            chan.out[pulSlots[c]] = (float2 *)ppDevOut[c];
+            continue;
+        }
         chan.slot[c] = pulSlots[c];
         chan.out[c] = (float2 *)ppDevOut[c];
         for (int m0 = 1; m0 < 4; m0++)
@@ -641,7 +691,7 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
         return 0;
     }
     HIP_TRY(pCtx, hipSetDevice(pCtx->device));
-    if (!ensure_fft_tables(pCtx))
+    if (!ensure_fft_tables(pCtx) || (pCtx->D == 16 && !ensure_bank_tables(pCtx)))
         return 0;
     return run_device(pCtx, pDevIn, ppDevOut[0], ullSamples, pullOutSamples, true, &chan);
 }
@@ -1088,12 +1138,15 @@ IF_FIR_API uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat
     }
     const int old = pCtx->in_i16;
     pCtx->in_i16 = (ulFormat == IF_FIR_INPUT_I16);
-    if (old != pCtx->in_i16 && pCtx->d_fft_tables) // the H table carries the sample format's scale: rebuilt on demand
+    if (old != pCtx->in_i16 && (pCtx->d_fft_tables || pCtx->d_fft_tables_bank)) // the tables carry the sample format's scale
     {
         HIP_TRY(pCtx, hipSetDevice(pCtx->device));
         HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
-        (void)hipFree(pCtx->d_fft_tables);
-        pCtx->d_fft_tables = nullptr;
+        if (pCtx->d_fft_tables)
+            (void)hipFree(pCtx->d_fft_tables);
+        if (pCtx->d_fft_tables_bank)
+            (void)hipFree(pCtx->d_fft_tables_bank);
+        pCtx->d_fft_tables = pCtx->d_fft_tables_bank = nullptr;
     }
     const uint32_t b = resolve_backend(pCtx, pCtx->backend_req);
     if (!backend_ok(pCtx, b))

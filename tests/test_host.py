@@ -289,6 +289,13 @@ def test_bench_line_contract_on_the_committed_run():
     assert r["traffic"] is None or 0.9 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.3 * r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    # round 3: the cold figure (same steps before any conditioning) is printed beside the settled one
+    assert d["cold_ms_per_step"] >= 0.9 * d["ms_per_step"] and 0.3 < r["cold_frac"] <= 1.1 * r["frac"]
+    assert abs(r["cold_frac"] - r["algorithmic_bytes_per_launch"] / (r["cold_kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-3
+    for cfg in ("fir127_2p26", "fir1023_2p28"):
+        auto = d["extra"]["configs"][cfg]["auto"]
+        if "traffic" in auto:   # (present once profiles/traffic.json holds the config's counter passes)
+            assert 0.95 < auto["traffic_over_algorithmic"] < 1.2 and auto["traffic"] > 0
     # value = samples of all ranks / wall time per step
     n = d["config"]["samples_per_channel"] * d["config"].get("channels", d["n_gpus"])
     assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3

@@ -207,3 +207,73 @@ def main_dec4():
 
 if __name__ == "__main__":
     main_dec4()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 16-slot filter bank at the channel rate (decimation 16, round 3): all 16 slots from ONE forward transform.
+#   after pass 2 + exchange 2: lane (g, k1), group i, slot n2: t[n2]   (k0 = 4g + i)
+#   channel s = prototype H moved up by s slots (s * 256 bins): H_s(k2) = H((k2 - s) mod 16) along the k2 axis
+#   folded spectrum Z_s(k0, k1) = sum_k2 H_s(k2) Y(k2) = sum_n2 t[n2] G0[n2] W16^(n2 s) = FFT16(t * G0)[s],
+#       G0[n2] = sum_k2 H(k0 + 16 k1 + 256 k2) W16^(n2 k2)                         (host table, same size as H)
+#   256-point inverse per channel, 4 channels (cs) at a time = inverse_dec4 without its first stage:
+#   X: element j = 4i + cs of lane (g, k1) -> lane (g, j), slot k1;   iFFT16 over k1 -> mu1;  twiddle conj W256^(k0 mu1)
+#   Y: element mu1 of lane (k0, cs) -> lane 4 mu1 + cs, slot k0;      iFFT16 over k0 -> mu0
+#   result: lane = 4 mu1 + cs, slot mu0:  y_s[16 mu0 + mu1]
+def bank16(x, h):
+    lane = np.arange(64)
+    g, m = lane // 16, lane % 16
+    H = np.fft.fft(h, N)
+    # forward up to exchange 2 (copy of forward() without pass 3)
+    p3 = forward(x)                                       # slot (i, k2): Y(k0 + 16 k1 + 256 k2)
+    t = np.zeros_like(p3)
+    for i in range(4):
+        t[16 * i:16 * i + 16] = np.fft.ifft(p3[16 * i:16 * i + 16], axis=0)        # back to t[n2] (model shortcut)
+    G0 = np.zeros((64, 64), dtype=np.complex128)         # slot (i, n2)
+    for i in range(4):
+        for n2 in range(16):
+            G0[16 * i + n2] = sum(H[(4 * g + i) + 16 * m + 256 * k2] * W(16, n2 * k2) for k2 in range(16))
+    z = np.zeros_like(p3)                                 # slot (i, s)
+    for i in range(4):
+        z[16 * i:16 * i + 16] = np.fft.fft(t[16 * i:16 * i + 16] * G0[16 * i:16 * i + 16], axis=0)
+    out = np.zeros((16, 256), dtype=np.complex128)
+    for b in range(4):
+        a = np.zeros((16, 64), dtype=np.complex128)       # slot j = 4 i + cs
+        for i in range(4):
+            for cs in range(4):
+                a[4 * i + cs] = z[16 * i + 4 * b + cs]
+        xx = np.zeros_like(a)
+        for gg in range(4):
+            xx[:, 16 * gg:16 * gg + 16] = a[:, 16 * gg:16 * gg + 16].T
+        j = lane % 16
+        i_l, cs_l = j // 4, j % 4
+        k0_l = 4 * g + i_l
+        bb = np.fft.ifft(xx, axis=0) * 16
+        for mu1 in range(16):
+            bb[mu1] = bb[mu1] * np.conj(W(256, k0_l * mu1))
+        y = np.zeros_like(bb)
+        for src in range(64):
+            for mu1 in range(16):
+                y[k0_l[src], 4 * mu1 + cs_l[src]] = bb[mu1, src]
+        c = np.fft.ifft(y, axis=0) * 16
+        for mu0 in range(16):
+            for ln in range(64):
+                out[4 * b + ln % 4, 16 * mu0 + ln // 4] = c[mu0, ln]
+    return out / N
+
+
+def main_bank16():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    h = rng.standard_normal(255)
+    out = bank16(x, h)
+    n = np.arange(255)
+    worst = 0.0
+    for s in range(16):
+        hs = h * np.exp(2j * np.pi * s * n / 16.0)        # prototype moved up by s/16 cycles/sample
+        full = np.convolve(x, hs)[:N]
+        worst = max(worst, np.max(np.abs(out[s][16:] - full[256::16])))
+    print("bank16 valid-part err (all 16 slots)", worst)
+
+
+if __name__ == "__main__":
+    main_bank16()
