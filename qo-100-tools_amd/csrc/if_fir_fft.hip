@@ -308,26 +308,39 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
 }
 
 // ---- block queue (two levels): if_fir_fft_queue.h, shared with the host simulation --------------------------------------
-// LDS image: slot counter at LDS_Q, ring of {local group, global group} words at LDS_Q + 16.
+// LDS image: the current-group word at LDS_Q, the look-ahead ring at LDS_Q + 16.
 struct DevQueue
 {
     char *smem;
     unsigned int *gqueue; // this launch's global ticket counter
     unsigned int *faultw; // third word of the queue block: bounded waits that expired (0 in a healthy launch)
     int lane;
+    __device__ __forceinline__ unsigned long long *cur() const { return reinterpret_cast<unsigned long long *>(smem + LDS_Q); }
     __device__ __forceinline__ unsigned long long *ring() const { return reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16); }
-    __device__ __forceinline__ unsigned slot_add()
+    static __device__ __forceinline__ unsigned long long uniform(unsigned long long v)
     {
-        unsigned s = 0;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    }
+    __device__ __forceinline__ unsigned long long cur_add()
+    {
+        unsigned long long w = 0;
         if (lane == 0)
-            s = __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(smem + LDS_Q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return __builtin_amdgcn_readfirstlane(s);
+            w = __hip_atomic_fetch_add(cur(), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return uniform(w);
+    }
+    __device__ __forceinline__ unsigned long long cur_load()
+    {
+        return uniform(__hip_atomic_load(cur(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    __device__ __forceinline__ void cur_store(unsigned long long v)
+    {
+        if (lane == 0)
+            __hip_atomic_store(cur(), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __device__ __forceinline__ unsigned long long ring_load(unsigned i)
     {
-        const unsigned long long e = __hip_atomic_load(&ring()[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)e), hi = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
-        return ((unsigned long long)hi << 32) | lo;
+        return uniform(__hip_atomic_load(&ring()[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     }
     __device__ __forceinline__ void ring_store(unsigned i, unsigned long long v)
     {
@@ -349,35 +362,6 @@ struct DevQueue
     __device__ __forceinline__ void pause() { __builtin_amdgcn_s_sleep(2); }
     __device__ __forceinline__ unsigned wgs() const { return gridDim.x; }
 };
-// global group of local group g if its ring entry has been published already, else -1 (never waits)
-__device__ __forceinline__ int64_t queue_peek(DevQueue &q, unsigned g)
-{
-    const unsigned long long e = q.ring_load(g & (Q_RING - 1));
-    return (unsigned)e == g ? (int64_t)(unsigned)(e >> 32) : -1;
-}
-
-// (development, diag 8 / 128) touch one dword of every 128-byte line of [base + first, base + first + n8k * 8 KiB): the lines
-// land in L2 / the memory-side cache ahead of the row loads.  The destination is v255, which the kernel never allocates
-// (it uses ~212 VGPRs; the clobber raises the count to 256 = still two waves per SIMD), so the loads are fire-and-forget.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void prefetch_span(const char *base, int64_t first, int64_t limit, int n8k, int lane)
-{
-    if (first < 0 || first >= limit)
-        return;
-    const uint64_t a = (uint64_t)(base + first);
-    const int64_t room = limit - first;
-    u32x4_t srd;
-    srd.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-    srd.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    srd.z = __builtin_amdgcn_readfirstlane((unsigned)(room > 0x7fffffffLL ? 0x7fffffffLL : room));
-    srd.w = 0x00020000u;
-    const unsigned voff = (unsigned)lane * 128u;
-    for (int k = 0; k < n8k; k++)
-    {
-        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)k * 8192u);
-        asm volatile("buffer_load_dword v255, %0, %1, %2 offen" ::"v"(voff), "s"(srd), "s"(soff) : "v255");
-    }
-}
 
 // common tail of the small inverses: a[j], j = 4 i + low (low = mu2 of the 1024-point inverse, or the channel-in-batch of the
 // 16-slot bank), k0 = 4 g + i, k1 = lane % 16:
@@ -466,10 +450,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     if (plain_start)
     {
         blk = (int64_t)blockIdx.x * FFT_WAVES + wid; // slot wid of local group 0 = global group blockIdx.x
-        // diag 4 (development, results stay correct): the second wave of every SIMD starts (diag >> 12) & 255 sleeps later
-        if ((diag & 4) && wid >= FFT_WAVES / 2)
-            for (int k = 0; k < ((diag >> 12) & 255); k++)
-                __builtin_amdgcn_s_sleep(32);
         const int64_t s0 = blk * L - OVL + n0 - in_shift;
         if (blk < nblocks && s0 >= 0 && !(diag & 1))
         {
@@ -488,15 +468,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         f4v_t *dst = reinterpret_cast<f4v_t *>(smem);
         for (int i = threadIdx.x; i < LDS_XB / 16; i += 512)
             dst[i] = src[i];
-        // block queue: slot counter 0; the first local group(s) are static, the rest of the ring is empty
+        // block queue (if_fir_fft_queue.h): the current-group word and the look-ahead ring
         if (threadIdx.x < Q_RING)
-        {
             reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16)[threadIdx.x] = queue_ring_init(threadIdx.x, blockIdx.x, gridDim.x);
-        }
         if (threadIdx.x == 0)
         {
-            // (the first FFT_WAVES slots = local group 0 were taken statically above)
-            *reinterpret_cast<unsigned int *>(smem + LDS_Q) = plain_start ? (unsigned)FFT_WAVES : 0u;
+            *reinterpret_cast<unsigned long long *>(smem + LDS_Q) = queue_cur_init(blockIdx.x, gridDim.x, plain_start);
             // the other global counter is the next launch's: zero it here (this launch never touches it)
             if (blockIdx.x == 0)
                 queue[qsel ^ 1u] = 0u;
@@ -565,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // diag 64 (development, results stay correct): waves 4-7 of every workgroup leave at once = one wave per SIMD
     // (occupancy experiment; the queue hands their share to the others)
     if (!plain_start)
-        blk = (diag & 32) ? 0 : ((diag & 64) && wid >= FFT_WAVES / 2) ? nblocks : queue_take(dq);
+        blk = (diag & 32) ? 0 : ((diag & 64) && wid >= FFT_WAVES / 2) ? nblocks : queue_take(dq, nblocks);
     // diag 32 (development, results stay correct): static wave-interleaved blocks, no queue: block = it * waves + wave
     const bool static_map = (diag & 32) != 0;
     const int act_waves = (diag & 64) ? FFT_WAVES / 2 : FFT_WAVES;
@@ -680,25 +657,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         {
             // taken here: the block's own rows have all landed and the next block's are not issued yet, so the wait
             // behind the (rare) global atomic inside drains nothing
-            unsigned lg = 0;
-            blk_next = queue_take(dq, &lg);
-            // diag 8 / 128 (development, results stay correct): the lines of the NEXT local group are touched ahead of time,
-            // 8: all 8 blocks by the wave that took slot 0 (one CU requests its 240 KB together), 128: block j by the taker of slot j
-            if (diag & (8 | 128))
-            {
-                const unsigned jn = (unsigned)blk_next & 7u;
-                if ((diag & 128) || jn == 0)
-                {
-                    const int64_t gg1 = queue_peek(dq, lg + 1);
-                    const int64_t b0 = gg1 * 8 + ((diag & 128) ? (int64_t)jn : 0);
-                    if (gg1 >= 0 && b0 < nblocks)
-                    {
-                        const int64_t f0 = b0 * L - OVL + n0 - in_shift;
-                        const int64_t nb = (int64_t)((diag & 128) ? FFT_N : 8 * L + OVL) * ISZ;
-                        prefetch_span(in, f0 * ISZ, N * ISZ, (int)((nb + 8191) / 8192), lane);
-                    }
-                }
-            }
+            blk_next = queue_take(dq, nblocks);
         }
         const int64_t s0n = blk_next * L - OVL + n0 - in_shift;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
@@ -729,6 +688,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             // 256-point inverses, four slots at a time (cs = slot % 4 takes the place of mu2 in the 1024-point inverse):
             // lane = 4 mu1 + cs, slot mu0 -> y_s[16 mu0 + mu1], s = 4 b + cs; each lane stores to ITS channel's buffer
             constexpr int MU0_FIRST = OVL_ROWS / 4;
+            constexpr int EARLY_B = I16 ? 3 : 1; // batches whose next-block rows are requested ahead of their inverse (no scratch)
             const int cs = lane & 3, mu1 = lane >> 2;
 #pragma unroll
             for (int b = 0; b < 4; b++)
@@ -741,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         a[4 * i + q] = r[phys(i, 4 * b + q)];
                 // these 16 registers are dead: refill them with rows of the next block (the last batch after its inverse,
                 // to keep the temporaries out of scratch)
-                if (b < EARLY_GROUPS && next_fast)
+                if (b < EARLY_B && next_fast)
                 {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
@@ -751,7 +711,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 }
                 cf c[16];
                 inverse_tail256(a, c, twe, xb, lane);
-                if (b >= EARLY_GROUPS && next_fast)
+                if (b >= EARLY_B && next_fast)
                 {
 #pragma unroll
                     for (int i = 0; i < 4; i++)

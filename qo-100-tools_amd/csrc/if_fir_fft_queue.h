@@ -4,19 +4,22 @@
 //
 // Blocks are handed out in GROUPS of QB consecutive blocks, one group at a time per workgroup, groups in global order:
 // at any moment the chip works on one compact window of the stream, and no wave holds work another one could do.
-//   * level 1, workgroup (LDS): a wave takes the next SLOT of its workgroup: slot s = block s % QB of local group s / QB;
+//   * level 1, workgroup (LDS): ONE 64-bit word holds the workgroup's current group, {global group, local group, next slot}.
+//     A wave takes a block with a single returning add on that word: what comes back names the block completely, so there
+//     is no window between "taking a slot" and "learning which block it is" (round 3; the round-2 queue read the group
+//     from a ring after the take, and a wave stalled between the two could in principle be lapped by the ring -- the host
+//     simulation produced exactly that).  The wave that takes the LAST slot of a group installs the next group's word;
+//     waves that find the group used up wait for that (bounded) and take again.
 //   * level 2, global: the wave that takes slot 0 of local group g draws the global group of local group g + Q_AHEAD with
-//     one returning atomic and publishes it in a ring of {local group, global group} words; local groups 0 .. Q_AHEAD-1
-//     are static (workgroup b: global groups b, wgs + b).
-// Round 3:
-//   * tickets are drawn IN LOCAL ORDER: the wave that fetches for local group i first waits until entry i-1 is published
-//     (its ticket has then been drawn), so a workgroup's global groups increase with the local group.  The first local
-//     group that is out of range therefore ends the stream for its workgroup: a wave that draws a block >= nblocks may
-//     leave at once without stranding an in-range group published for a later local group;
-//   * the first slot of every wave is static (wave w = slot w of local group 0), so that the first block's rows can be
-//     requested before the tables are copied; wave 0 owes the fetch for local group Q_AHEAD (queue_start);
-//   * every wait is bounded: a wave that does not see its ring entry after Q_SPIN_LIMIT polls leaves (and counts a fault
-//     in the queue block's third word) instead of spinning for ever.
+//     one returning atomic and publishes it in a small look-ahead ring (read once, by the installer of that group).  Local
+//     groups 0 and 1 are static (workgroup b: global groups b and wgs + b); group 0 is also TAKEN statically (wave w =
+//     slot w, so the first block's rows can be requested before the tables are copied): the word starts at group 1 and wave
+//     0 owes the fetch for group Q_AHEAD (queue_start).
+// Tickets are drawn IN LOCAL ORDER: the fetch for local group i first waits until entry i - 1 is published, so a
+// workgroup's global groups increase with the local group and the first group that reaches past the end of the stream ends
+// it for the workgroup: a wave that draws a block >= nblocks leaves at once, and a wave that finds a used-up group leaves
+// when that group already reaches the end.  Every wait is bounded: after Q_SPIN_LIMIT polls a wave leaves and counts a
+// fault (third word of the queue block) instead of spinning for ever.
 // One global atomic per QB blocks (a single address takes ~88 atomics/us; 70 k blocks in 0.5 ms would be 140/us), two
 // groups of slack before anybody needs its result.
 #pragma once
@@ -32,14 +35,27 @@ namespace if_fir
 {
 
 constexpr unsigned QB = 8;        // blocks per group = waves per workgroup
-constexpr unsigned Q_AHEAD = 2;   // groups fetched ahead = static groups per workgroup
-constexpr unsigned Q_RING = 16;   // ring entries (a power of two, > Q_AHEAD + 1)
+constexpr unsigned Q_AHEAD = 2;   // groups fetched ahead; local groups 0 .. Q_AHEAD-1 are static
+constexpr unsigned Q_RING = 4;    // look-ahead ring entries (a power of two >= Q_AHEAD + 2)
 constexpr unsigned Q_SPIN_LIMIT = 1u << 22;
 constexpr int64_t Q_NONE = (int64_t)1 << 46; // "no block" (beyond any stream, small enough to be multiplied by a block length)
 
+// current-group word: [63:32] global group, [31:8] local group (24 bits), [7:0] next slot
+IF_FIR_Q_FN unsigned long long queue_word(unsigned global_group, unsigned local_group, unsigned slot)
+{
+    return ((unsigned long long)global_group << 32) | ((unsigned long long)(local_group & 0xffffffu) << 8) | slot;
+}
+// look-ahead ring entry: [63:32] global group, [31:0] local group
+IF_FIR_Q_FN unsigned long long queue_entry(unsigned global_group, unsigned local_group)
+{
+    return ((unsigned long long)global_group << 32) | local_group;
+}
+
 // P (platform) provides, wave-uniformly:
-//   unsigned slot_add()                       LDS fetch-and-increment of the workgroup's slot counter
-//   unsigned long long ring_load(unsigned i)  ring[i]
+//   unsigned long long cur_add()              returning add of 1 on the current-group word (LDS)
+//   unsigned long long cur_load()
+//   void cur_store(unsigned long long)
+//   unsigned long long ring_load(unsigned i)  look-ahead ring (LDS)
 //   void ring_store(unsigned i, unsigned long long v)
 //   unsigned ticket()                         global fetch-and-increment of the launch's ticket counter
 //   void fault()                              count a bounded-wait expiry
@@ -47,12 +63,12 @@ constexpr int64_t Q_NONE = (int64_t)1 << 46; // "no block" (beyond any stream, s
 //   unsigned wgs()                            workgroups of the launch
 
 template <class P>
-IF_FIR_Q_FN bool queue_wait_entry(P &p, unsigned g, unsigned long long &e)
+IF_FIR_Q_FN bool queue_wait_entry(P &p, unsigned i, unsigned long long &e)
 {
     for (unsigned spin = 0; spin < Q_SPIN_LIMIT; spin++)
     {
-        e = p.ring_load(g & (Q_RING - 1));
-        if ((unsigned)e == g)
+        e = p.ring_load(i & (Q_RING - 1));
+        if ((unsigned)e == i)
             return true;
         p.pause();
     }
@@ -65,39 +81,67 @@ template <class P>
 IF_FIR_Q_FN void queue_fetch(P &p, unsigned i)
 {
     unsigned long long prev;
-    if (!queue_wait_entry(p, i - 1, prev)) // entries 0 .. Q_AHEAD-1 exist from the start, so i - 1 >= Q_AHEAD - 1 is defined
+    if (!queue_wait_entry(p, i - 1, prev)) // (entries 0 .. Q_AHEAD-1 exist from the start)
         return;
     const unsigned t = p.ticket();
-    p.ring_store(i & (Q_RING - 1), ((unsigned long long)(Q_AHEAD * p.wgs() + t) << 32) | (unsigned long long)i);
+    p.ring_store(i & (Q_RING - 1), queue_entry(Q_AHEAD * p.wgs() + t, i));
 }
 
-// the fetch the static first slot 0 (wave 0) owes: call once per workgroup after the ring has been initialised
+// the fetch the static slot 0 of local group 0 (wave 0) owes: once per workgroup, after the LDS words are initialised
 template <class P>
 IF_FIR_Q_FN void queue_start(P &p)
 {
     queue_fetch(p, Q_AHEAD);
 }
 
-// next block of this wave (Q_NONE: leave); *local_group (optional) receives the local group of the slot
+// next block of this wave (>= nblocks: leave); *local_group (optional) receives the local group of the block
 template <class P>
-IF_FIR_Q_FN int64_t queue_take(P &p, unsigned *local_group = nullptr)
+IF_FIR_Q_FN int64_t queue_take(P &p, int64_t nblocks, unsigned *local_group = nullptr)
 {
-    const unsigned s = p.slot_add();
-    const unsigned g = s / QB, j = s % QB;
-    if (j == 0)
-        queue_fetch(p, g + Q_AHEAD);
-    unsigned long long e;
-    if (!queue_wait_entry(p, g, e))
-        return Q_NONE;
-    if (local_group)
-        *local_group = g;
-    return (int64_t)(unsigned)(e >> 32) * QB + j;
+    for (unsigned spin = 0; spin < Q_SPIN_LIMIT; spin++)
+    {
+        const unsigned long long w = p.cur_add();
+        const unsigned gg = (unsigned)(w >> 32), g = (unsigned)(w >> 8) & 0xffffffu, j = (unsigned)w & 0xffu;
+        if (j < QB)
+        {
+            if (j == 0)
+                queue_fetch(p, g + Q_AHEAD);
+            if (j == QB - 1)
+            {
+                // last slot: install the next group (its entry was fetched Q_AHEAD groups ago)
+                unsigned long long e;
+                if (queue_wait_entry(p, g + 1, e))
+                    p.cur_store(queue_word((unsigned)(e >> 32), g + 1, 0));
+            }
+            if (local_group)
+                *local_group = g;
+            return (int64_t)gg * QB + j;
+        }
+        // the group is used up.  If it already reaches the end of the stream no later group is in range (ordered tickets)
+        if ((int64_t)gg * QB + QB - 1 >= nblocks)
+            return Q_NONE;
+        // otherwise wait (without adding again) until the taker of its last slot has installed the next group
+        for (; spin < Q_SPIN_LIMIT; spin++)
+        {
+            const unsigned long long c = p.cur_load();
+            if (((unsigned)(c >> 8) & 0xffffffu) != g)
+                break;
+            p.pause();
+        }
+    }
+    p.fault();
+    return Q_NONE;
 }
 
-// initial ring image of workgroup `wg`: entry i (i < Q_RING)
+// initial LDS image of workgroup `wg`: the current-group word (static_first: local group 1 = global group wgs + wg, group 0
+// being taken statically; else local group 0) and look-ahead ring entry i
+IF_FIR_Q_FN unsigned long long queue_cur_init(unsigned wg, unsigned wgs, bool static_first)
+{
+    return static_first ? queue_word(wgs + wg, 1, 0) : queue_word(wg, 0, 0);
+}
 IF_FIR_Q_FN unsigned long long queue_ring_init(unsigned i, unsigned wg, unsigned wgs)
 {
-    return i < Q_AHEAD ? (((unsigned long long)(i * wgs + wg)) << 32) | i : ~0ull;
+    return i < Q_AHEAD ? queue_entry(i * wgs + wg, i) : ~0ull;
 }
 
 } // namespace if_fir

@@ -19,7 +19,7 @@ using namespace if_fir;
 
 struct Workgroup
 {
-    std::atomic<unsigned> cnt{0};
+    std::atomic<unsigned long long> cur{0};
     std::atomic<unsigned long long> ring[Q_RING];
 };
 
@@ -31,7 +31,9 @@ struct HostQueue
 {
     Workgroup *wg;
     std::mt19937 *rng;
-    unsigned slot_add() { return wg->cnt.fetch_add(1, std::memory_order_relaxed); }
+    unsigned long long cur_add() { return wg->cur.fetch_add(1, std::memory_order_relaxed); }
+    unsigned long long cur_load() { return wg->cur.load(std::memory_order_relaxed); }
+    void cur_store(unsigned long long v) { wg->cur.store(v, std::memory_order_relaxed); }
     unsigned long long ring_load(unsigned i) { return wg->ring[i].load(std::memory_order_relaxed); }
     void ring_store(unsigned i, unsigned long long v) { wg->ring[i].store(v, std::memory_order_relaxed); }
     unsigned ticket()
@@ -64,7 +66,7 @@ int main(int argc, char **argv)
     std::vector<Workgroup> wg(g_wgs);
     for (unsigned b = 0; b < g_wgs; b++)
     {
-        wg[b].cnt.store(QB); // the first QB slots (local group 0) are taken statically
+        wg[b].cur.store(queue_cur_init(b, g_wgs, true)); // local group 0 is taken statically
         for (unsigned i = 0; i < Q_RING; i++)
             wg[b].ring[i].store(queue_ring_init(i, b, g_wgs));
     }
@@ -90,9 +92,11 @@ int main(int argc, char **argv)
                     const unsigned r = rng();
                     if ((r & 15) == 0)
                         std::this_thread::sleep_for(std::chrono::microseconds(50 + r % 300));
+                    else if ((r & 1023) == 1)
+                        std::this_thread::sleep_for(std::chrono::milliseconds(3)); // a wave that falls far behind its workgroup
                     else if ((r & 3) == 0)
                         std::this_thread::yield();
-                    blk = queue_take(q);
+                    blk = queue_take(q, nblocks);
                 }
             });
     for (auto &t : waves)

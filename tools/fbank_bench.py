@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """fbank_bench.py — uniform filter bank (if_fir_channelizer_process_device) against the same channels
 computed one at a time (if_fir_set_nco contexts): time per pass over a 2^log2n-sample wideband stream, whole-output
-comparison of every channel, one JSON line.  usage: python tools/fbank_bench.py [channels=8] [log2n=28] [taps=255]"""
+comparison of every channel, one JSON line.
+usage: python tools/fbank_bench.py [channels=8] [log2n=28] [taps=255] [decimation=4]   (decimation 4: 4x oversampled fs/16
+channels; 16: the channel rate, all 16 slots from one forward transform, round 3)"""
 import json
 import os
 import sys
@@ -17,13 +19,14 @@ def main():
     nch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 28
     taps_n = int(sys.argv[3]) if len(sys.argv) > 3 else 255
+    dec = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     n = 1 << log2n
     fir = g.load_pkg().if_fir
     torch.cuda.set_device(0)
-    taps = fir.bpf_design(taps_n, 0.0, 0.03)
-    slots = [(2 * c + 1) % 16 for c in range(nch)]
+    taps = fir.bpf_design(taps_n, 0.0, 0.03 if dec == 4 else 0.02)
+    slots = [(2 * c + 1) % 16 for c in range(nch)] if nch <= 8 else list(range(nch))
     x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
-    with fir.IfFir(taps, 4, 0, dev=True) as f:
+    with fir.IfFir(taps, dec, 0, dev=True) as f:
         m = f.out_count(n)
         outs = [torch.empty(2 * m, dtype=torch.float32, device="cuda") for _ in range(nch)]
         torch.cuda.synchronize()
@@ -51,7 +54,7 @@ def main():
     worst = 0.0
     ms_single = 0.0
     for c, s in enumerate(slots):
-        with fir.IfFir(taps, 4, 0, dev=True) as f1:
+        with fir.IfFir(taps, dec, 0, dev=True) as f1:
             f1.set_nco(s / 16.0 if s <= 8 else s / 16.0 - 1.0)   # slots above 8 are negative frequencies
             f1.set_stream(stream.cuda_stream)
             f1.process_device(x.data_ptr(), ref.data_ptr(), n)
@@ -66,9 +69,10 @@ def main():
             e1.record(stream)
             torch.cuda.synchronize()
             ms_single += e0.elapsed_time(e1) / 10
-    bytes_alg = (8.0 + nch * 2.0) * n
+    bytes_alg = (8.0 + nch * 8.0 / dec) * n   # one read of the wideband stream + every channel's output
     print(json.dumps({
-        "workload": "uniform filter bank: %d channels x (%d-tap prototype, decimate-by-4) from one 2^%d-sample stream" % (nch, taps_n, log2n),
+        "workload": "uniform filter bank: %d channels x (%d-tap prototype, decimate-by-%d) from one 2^%d-sample stream" % (nch, taps_n, dec, log2n),
+        "bytes_per_input_sample": 8.0 + nch * 8.0 / dec,
         "slots": slots, "filter_bank_ms": round(ms_bank, 4), "one_channel_at_a_time_ms": round(ms_single, 4),
         "speedup": round(ms_single / ms_bank, 2),
         "input_msamples_per_s": round(n / ms_bank / 1e3, 1), "channel_output_msamples_per_s": round(nch * m / ms_bank / 1e3, 1),
