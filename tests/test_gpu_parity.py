@@ -746,7 +746,7 @@ def test_filter_bank_at_the_channel_rate(fir, oracle, torch_cuda, t, i16):
         xd = torch.from_numpy(x).cuda()
         cuts = [0, 1, 6, 4103, 40_001, 40_018, 120_007, n]
     refs = {s: oracle.fir_nco_f64(taps, x, d, (s << 28) & 0xFFFFFFFF) for s in range(16)}
-    with fir.IfFir(taps, d, 0, dev=True) as f:
+    with fir.IfFir(taps, d, n, dev=True) as f:
         if i16:
             f.set_input_format(fir.INPUT_I16)
         assert f.get_backend() == fir.BACKEND_HIP_FFT
