@@ -464,13 +464,13 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // samples with the second partition's table and adds its result to what the first launch stored
     static_assert(!ACC || (!DEC4 && !CHAN && OVL_ROWS == 32), "accumulating store: full-rate pipeline, 32 overlap rows");
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
-    static_assert(CHAN == 0 || ((CHAN == 4 || CHAN == 16) && DEC4 && !NCO), "the filter bank is a decimating variant (4 or 16)");
+    static_assert(CHAN == 0 || ((CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4 && !NCO), "the filter bank is a decimating variant (4, 8, 16)");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
     const char *in = reinterpret_cast<const char *>(in_);
     constexpr int L = FFT_N - OVL;         // new input samples per block
-    constexpr int LOUT = CHAN == 16 ? L / 16 : DEC4 ? L / 4 : L; // outputs per block (per channel)
+    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : DEC4 ? L / 4 : L; // outputs per block (per channel)
     constexpr int EARLY_GROUPS = IF_FIR_FFT_EARLY_GROUPS; // dec4: batches of next-block loads issued during pass 3
     constexpr int LAUX = IF_FIR_FFT_LOAD_AUX(OVL_ROWS); // cache policy of the row loads
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -782,6 +782,91 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 }
             }
         }
+        else if constexpr (CHAN == 8)
+        {
+            // ---- filter bank at decimation 8 (fs/16 slots, 2x oversampled channels; tools/fft_model.py bank8) ------------
+            // First radix-2 stage of pass 3 once, in place: r[phys(i, a)] = w0[a] = t[a] + t[a+8], r[phys(i, a+8)] = w1[a].
+            // Channel at slot s:  Z_s(k2') = sum_a w_{k2'}[a] W16^(a s) G_q[a],  q = (k2' - s) mod 2 (host table G, kernel
+            // arguments W16^(a s)); 512-point inverse, two channels per small inverse (low = 2 ch + mu2):
+            // lane = 4 mu1 + 2 ch + mu2, slot mu0 -> y_ch[32 mu0 + 2 mu1 + mu2]
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int a8 = 0; a8 < 8; a8++)
+                {
+                    const cf u = r[phys(i, a8)], v = r[phys(i, a8 + 8)];
+                    r[phys(i, a8)] = u + v;
+                    r[phys(i, a8 + 8)] = u - v;
+                }
+            constexpr int MU0_FIRST = OVL_ROWS / 4;
+            const int nch = (int)chan.count;
+            for (int cp = 0; cp < nch; cp += 2)
+            {
+                const bool last = cp + 2 >= nch; // the w values die with the last pair: refill with the next block
+                cf a[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++)
+                    {
+                        const int c = (cp + ch < nch) ? cp + ch : nch - 1; // odd count: the last channel twice, stored once
+                        const int par = (int)chan.slot[c] & 1;
+                        const f2v *g0 = hp + (i * 16 + 8 * par) * 64 + lane;       // k2' = 0: q = s & 1       (+ a * 64 entries)
+                        const f2v *g1 = hp + (i * 16 + 8 * (1 - par)) * 64 + lane; // k2' = 1: q = (1 - s) & 1
+                        cf z0 = cmul_v<false>(r[phys(i, 0)], g0[0]);
+                        cf z1 = cmul_v<false>(r[phys(i, 8)], g1[0]);
+#pragma unroll
+                        for (int a8 = 1; a8 < 8; a8++)
+                        {
+                            const cf tw = {chan.tw[c][2 * (a8 - 1)], chan.tw[c][2 * (a8 - 1) + 1]};
+                            z0 = cmac_v(z0, cmul_s<false>(r[phys(i, a8)], tw), g0[a8 * 64]);
+                            z1 = cmac_v(z1, cmul_s<false>(r[phys(i, a8 + 8)], tw), g1[a8 * 64]);
+                        }
+                        a[4 * i + 2 * ch] = z0 + z1;
+                        a[4 * i + 2 * ch + 1] = cmul_v<true>(z0 - z1, twd[(i * 4 + 2) * 64 + lane]); // conj W512^(16 k1 + k0)
+                    }
+                    if (last && i < EARLY_GROUPS && next_fast)
+                    {
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                    }
+                }
+                cf c[16];
+                inverse_tail256(a, c, twe, xb, lane);
+                if (last && next_fast)
+                {
+#pragma unroll
+                    for (int i = EARLY_GROUPS; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                }
+                // mix-down: exp(-j 2 pi s a / 16), a = abs0 + n0 + 8 m: the call constant rot0 times (-1)^(s m); m = obase +
+                // 32 (mu0 - first) + 2 mu1 + mu2 with obase even, so the sign is (-1)^(s mu2)
+                const int chl = (lane >> 1) & 1, cl = cp + chl;
+                const int c1 = (cp + 1 < nch) ? cp + 1 : nch - 1;
+                float2 *po = chl ? chan.out[c1] : chan.out[cp];
+                const cf r0 = chl ? (cf){chan.rot0[c1][0], chan.rot0[c1][1]} : (cf){chan.rot0[cp][0], chan.rot0[cp][1]};
+                const int sl = chl ? (int)chan.slot[c1] : (int)chan.slot[cp];
+                const cf wl = ((sl & lane) & 1) ? (cf){-r0.x, -r0.y} : r0;
+                const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
+                if (cl < nch && !(diag & 2))
+                {
+#pragma unroll
+                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    {
+                        const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
+                        if (idx < M)
+                        {
+                            const cf v = cmul_v<false>(c[mu0], wl);
+                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                        }
+                    }
+                }
+            }
+        }
         else if constexpr (CHAN == 4)
         {
             // ---- uniform filter bank: one forward transform, one decimated inverse per channel ---------
@@ -1070,7 +1155,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 {
     auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN, ACC>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
-    constexpr int LOUT = CHAN == 16 ? L / 16 : DEC4 ? L / 4 : L;
+    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : DEC4 ? L / 4 : L;
     static DeviceSetup setup;
     int ncus = 0;
     {
@@ -1149,8 +1234,10 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
 {
     if (a.chan)
     {
-        if ((a.D != 4 && a.D != 16) || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
+        if ((a.D != 4 && a.D != 8 && a.D != 16) || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
             return hipErrorInvalidConfiguration;
+        if (a.D == 8) // per channel (pairs share a small inverse); chan->tw[] = W16^(a slot), a = 1..7
+            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 8>(a) : launch_fft_t<ROWS, true, false, false, 8>(a);
         if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
             return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 16>(a) : launch_fft_t<ROWS, true, false, false, 16>(a);
         return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 4>(a) : launch_fft_t<ROWS, true, false, false, 4>(a);
@@ -1329,6 +1416,28 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                 hd[2 * ((i * 16 + k2) * 64 + lane) + 0] = re / 4096.0 * in_scale; // in_scale: 2^-15 for raw int16 samples
                 hd[2 * ((i * 16 + k2) * 64 + lane) + 1] = im / 4096.0 * in_scale;
             }
+    if (bank == 8)
+    {
+        // filter bank at decimation 8: G_q[a] = W16^(a q) sum_j H(k0 + 16 k1 + 256 (q + 2 j)) W8^(a j) at ((i*16 + 8 q + a)*64 + lane)
+        // (second stage of pass 3, the multiplication by the slot's H and the 8-way alias fold merged; kernel, CHAN == 8)
+        for (int i = 0; i < 4; i++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int q = 0; q < 2; q++)
+                    for (int a8 = 0; a8 < 8; a8++)
+                    {
+                        double re = 0.0, im = 0.0;
+                        for (int j = 0; j < 8; j++)
+                        {
+                            const double *h = &hd[2 * ((i * 16 + q + 2 * j) * 64 + lane)];
+                            const int e = (256 * a8 * q + 512 * a8 * j) & 4095;
+                            re += h[0] * ct[e] - h[1] * st[e];
+                            im += h[0] * st[e] + h[1] * ct[e];
+                        }
+                        hp[2 * ((i * 16 + 8 * q + a8) * 64 + lane) + 0] = (float)re;
+                        hp[2 * ((i * 16 + 8 * q + a8) * 64 + lane) + 1] = (float)im;
+                    }
+        return;
+    }
     if (bank == 16)
     {
         // 16-slot filter bank at the channel rate: G0[n2] = sum_k2 H(k0 + 16 k1 + 256 k2) W16^(n2 k2) at ((i*16 + n2)*64 + lane)

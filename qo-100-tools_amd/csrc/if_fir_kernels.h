@@ -23,7 +23,7 @@ struct ChanArgs
 {
     uint32_t count;
     uint32_t slot[CHAN_MAX];
-    float tw[CHAN_MAX][6];   // W16^(m0 slot), m0 = 1..3 (re, im)
+    float tw[CHAN_MAX][14];  // decimation 4: W16^(m0 slot), m0 = 1..3 (re, im); decimation 8: W16^(a slot), a = 1..7
     float rot0[CHAN_MAX][2]; // exp(-j 2 pi slot (abs0 + n0) / 16): mix-down phase at this call's first output
     float2 *out[CHAN_MAX];   // device, M samples each
 };
@@ -122,7 +122,7 @@ struct FftSchedule
 };
 void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s); // host-only: run-queue layout of a launch
 hipError_t launch_fft(const LaunchArgs &a);
-// bank = 16: the table of the 16-slot filter bank at the channel rate (decimation 16) in place of H
+// bank = 8 / 16: the merged table of the filter bank at decimation 8 / 16 in place of H
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale, float *tables,
                       int bank = 0);
 

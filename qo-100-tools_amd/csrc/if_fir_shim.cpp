@@ -181,7 +181,7 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
     return 1;
 }
 
-// table image of the 16-slot filter bank at the channel rate (decimation-16 contexts, real taps, no NCO)
+// merged table image of the filter bank at decimation 8 or 16 (real taps, no NCO)
 static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
 {
     if (ctx->d_fft_tables_bank)
@@ -192,7 +192,7 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
         set_err(ctx, "filter-bank tables: out of host memory");
         return 0;
     }
-    if_fir::fft_build_tables(ctx->h_taps, ctx->T, 0, ctx->D, 0u, ctx->in_i16 ? 0x1p-15 : 1.0, tab, 16);
+    if_fir::fft_build_tables(ctx->h_taps, ctx->T, 0, ctx->D, 0u, ctx->in_i16 ? 0x1p-15 : 1.0, tab, ctx->D);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables_bank, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
@@ -586,7 +586,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
             chan->rot0[c][1] = (float)sin(-2.0 * M_PI * (double)e / 16.0);
         }
         a.chan = chan;
-        if (ctx->D == 16)
+        if (ctx->D == 16 || ctx->D == 8)
             a.fft_tables = ctx->d_fft_tables_bank;
     }
     a.queue_base = &ctx->queue_base;
@@ -641,10 +641,10 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
         set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot and output arrays", if_fir::CHAN_MAX);
         return 0;
     }
-    if ((pCtx->D != 4 && pCtx->D != 16) || pCtx->ctaps || pCtx->nco_word || !if_fir::fft_supported(pCtx->T, pCtx->D) ||
-        if_fir::fft_two_partitions(pCtx->T))
+    if ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || pCtx->ctaps || pCtx->nco_word ||
+        !if_fir::fft_supported(pCtx->T, pCtx->D) || if_fir::fft_two_partitions(pCtx->T))
     {
-        set_err(pCtx, "if_fir_channelizer_process_device: needs real taps (<= 3073), decimation 4 or 16, no NCO");
+        set_err(pCtx, "if_fir_channelizer_process_device: needs real taps (<= 3073), decimation 4, 8 or 16, no NCO");
         return 0;
     }
     if (pCtx->backend != IF_FIR_BACKEND_HIP_FFT)
@@ -678,7 +678,7 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
         }
         chan.slot[c] = pulSlots[c];
         chan.out[c] = (float2 *)ppDevOut[c];
-        for (int m0 = 1; m0 < 4; m0++)
+        for (int m0 = 1; m0 < 8; m0++) // decimation 4 uses the first three
         {
             const double a = -2.0 * M_PI * (double)((m0 * pulSlots[c]) & 15u) / 16.0; // W16^(m0 slot)
             chan.tw[c][2 * (m0 - 1) + 0] = (float)cos(a);
@@ -691,7 +691,7 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
         return 0;
     }
     HIP_TRY(pCtx, hipSetDevice(pCtx->device));
-    if (!ensure_fft_tables(pCtx) || (pCtx->D == 16 && !ensure_bank_tables(pCtx)))
+    if (!ensure_fft_tables(pCtx) || (pCtx->D != 4 && !ensure_bank_tables(pCtx)))
         return 0;
     return run_device(pCtx, pDevIn, ppDevOut[0], ullSamples, pullOutSamples, true, &chan);
 }

@@ -277,3 +277,85 @@ def main_bank16():
 
 if __name__ == "__main__":
     main_bank16()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# filter bank at decimation 8 (fs/16 slots, 2x oversampled channels, round 3): per channel, two channels per small inverse.
+#   first radix-2 stage of pass 3 once:  w0[a] = t[a] + t[a+8],  w1[a] = t[a] - t[a+8]          (a = 0..7)
+#   channel s, k2' in {0, 1}:  Z_s(k0, k1, k2') = sum_a w_{k2'}[a] * W16^(a s) * G_q[a],  q = (k2' - s) mod 2,
+#       G_q[a] = W16^(a q) * sum_j H(k0 + 16 k1 + 256 (q + 2 j)) W8^(a j)                     (host table, same size as H)
+#   512-point inverse (2 x 16 x 16), two channels at a time: stage A' = 2-point butterfly over k2' -> mu2, twiddle
+#   conj W512^((16 k1 + k0) mu2), then the common tail with low = 2 ch + mu2:
+#   result: lane = 4 mu1 + 2 ch + mu2, slot mu0:  y_ch[32 mu0 + 2 mu1 + mu2]
+def bank8(x, h, slots):
+    lane = np.arange(64)
+    g, m = lane // 16, lane % 16
+    H = np.fft.fft(h, N)
+    p3 = forward(x)
+    t = np.zeros_like(p3)
+    for i in range(4):
+        t[16 * i:16 * i + 16] = np.fft.ifft(p3[16 * i:16 * i + 16], axis=0)
+    G = np.zeros((64, 64), dtype=np.complex128)          # slot (i, q, a) := 16 i + 8 q + a
+    for i in range(4):
+        for q in range(2):
+            for a in range(8):
+                G[16 * i + 8 * q + a] = W(16, a * q) * sum(H[(4 * g + i) + 16 * m + 256 * (q + 2 * j)] * W(8, a * j) for j in range(8))
+    w = np.zeros_like(t)                                  # slot (i, k2', a) := 16 i + 8 k2' + a
+    for i in range(4):
+        for a in range(8):
+            w[16 * i + a] = t[16 * i + a] + t[16 * i + a + 8]
+            w[16 * i + 8 + a] = t[16 * i + a] - t[16 * i + a + 8]
+    out = {}
+    for pair in range(0, len(slots), 2):
+        chans = slots[pair:pair + 2]
+        a_ = np.zeros((16, 64), dtype=np.complex128)      # slot 4 i + 2 ch + mu2
+        for ch, s in enumerate(chans):
+            for i in range(4):
+                z = []
+                for k2p in range(2):
+                    q = (k2p - s) % 2
+                    z.append(sum(w[16 * i + 8 * k2p + a] * W(16, a * s) * G[16 * i + 8 * q + a] for a in range(8)))
+                for mu2 in range(2):
+                    v = z[0] + (-1) ** mu2 * z[1]
+                    a_[4 * i + 2 * ch + mu2] = v * np.conj(W(512, (16 * m + 4 * g + i) * mu2))
+        xx = np.zeros_like(a_)
+        for gg in range(4):
+            xx[:, 16 * gg:16 * gg + 16] = a_[:, 16 * gg:16 * gg + 16].T
+        j = lane % 16
+        i_l, low_l = j // 4, j % 4
+        k0_l = 4 * g + i_l
+        bb = np.fft.ifft(xx, axis=0) * 16
+        for mu1 in range(16):
+            bb[mu1] = bb[mu1] * np.conj(W(256, k0_l * mu1))
+        y = np.zeros_like(bb)
+        for src in range(64):
+            for mu1 in range(16):
+                y[k0_l[src], 4 * mu1 + low_l[src]] = bb[mu1, src]
+        c = np.fft.ifft(y, axis=0) * 16
+        for ch, s in enumerate(chans):
+            o = np.zeros(512, dtype=np.complex128)
+            for mu0 in range(16):
+                for ln in range(64):
+                    if (ln >> 1) & 1 == ch:
+                        o[32 * mu0 + 2 * (ln >> 2) + (ln & 1)] = c[mu0, ln]
+            out[s] = o / N
+    return out
+
+
+def main_bank8():
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    h = rng.standard_normal(255)
+    slots = [0, 1, 2, 5, 8, 11, 14, 15]
+    out = bank8(x, h, slots)
+    n = np.arange(255)
+    worst = 0.0
+    for s in slots:
+        hs = h * np.exp(2j * np.pi * s * n / 16.0)
+        full = np.convolve(x, hs)[:N]
+        worst = max(worst, np.max(np.abs(out[s][32:] - full[256::8])))
+    print("bank8 valid-part err", worst)
+
+
+if __name__ == "__main__":
+    main_bank8()
