@@ -32,7 +32,7 @@ SGPR_RING_BASE = 36      # s[36:99]: 4 blocks x 16 taps
 SGPR_RING_BLOCKS = 4
 
 
-def gen_walk(T, D, R, SEG, Q, U, W=1):
+def gen_walk(T, D, R, SEG, Q, U, W=1, nodrain=False):
     """Returns (function name, asm lines, clobber list, n_tot)."""
     assert T % 2 == 1 and U in (1, 2)
     DR = D * R
@@ -148,7 +148,7 @@ def gen_walk(T, D, R, SEG, Q, U, W=1):
     # ---- steps ------------------------------------------------------------------------------------------------
     started = set()                              # (r) accumulators that hold a live partial sum
     for ui in range(nunits):
-        if ui in drain_at:
+        if ui in drain_at and not nodrain:   # nodrain: TIMING STUDY ONLY (a tap block is used without waiting for it)
             emit("s_waitcnt lgkmcnt(0)")
         for b in smem_at.get(ui, []):
             emit_smem(b)
@@ -207,7 +207,8 @@ CONFIGS = [
     # (T, D, R, SEG, [(suffix, Q, U), ...])
     # only what the library launches: the decimating walks (the D = 1 wave-kernel walks of round 1 were reachable through
     # tuning variants only -- the D = 1 configurations run the compiler-scheduled workgroup kernel -- and were removed)
-    (255, 4, 8, 32, [("", 4, 1), ("_b128", 2, 2), ("_b128_w2", 3, 2, 2), ("_b128_w3", 3, 2, 3), ("_b128_q4w2", 4, 2, 2)]),
+    (255, 4, 8, 32, [("", 4, 1), ("_b128", 2, 2), ("_b128_w2", 3, 2, 2), ("_b128_w3", 3, 2, 3), ("_b128_q4w2", 4, 2, 2),
+                     ("_b128_nodrain", 2, 2, 1, True)]),
     (127, 4, 8, 32, [("", 4, 1)]),
 ]
 
@@ -225,7 +226,8 @@ def main():
             for variant in variants:
                 suffix, Q, U = variant[:3]
                 W = variant[3] if len(variant) > 3 else 1
-                name, lines, clobbers, meta = gen_walk(T, D, R, SEG, Q, U, W)
+                nodrain = variant[4] if len(variant) > 4 else False
+                name, lines, clobbers, meta = gen_walk(T, D, R, SEG, Q, U, W, nodrain)
                 emit_function(f, name, lines, clobbers, meta, suffix)
         f.write("} // namespace if_fir\n")
     print("wrote", os.path.normpath(args.out))
