@@ -134,6 +134,77 @@ def cpu_baseline(taps_arr, decim, budget_s=10.0):
                       (taps_arr.size, decim, reps, "-march=native" if handle is not None else "x86-64-v3")}
 
 
+def live_traffic(workload, backend, timeout_s=150.0):
+    """HBM bytes per launch of this workload's kernel measured ON THIS BOX, in this run: two rocprofv3 --pmc passes
+    (FETCH_SIZE, WRITE_SIZE; each in its own pass, no trace domains) around a 3-step child run of this script.  Must be
+    called BEFORE this process touches the GPU (the children are separate processes).  Returns None when the profiler is
+    missing, refuses, hangs (bounded by timeout_s per pass) or when this process already runs under a profiler."""
+    import csv
+    import glob
+    import shutil
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_LIBRARY_CTOR") or \
+            os.environ.get("IF_FIR_BENCH_NO_PROFILER"):
+        return None
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out = tempfile.mkdtemp(prefix="if_fir_traffic_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, ctr)
+            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", workload, "--backend", backend, "--traffic-child"]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None
+            per_kernel = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == ctr and "if_fir::fir_" in r["Kernel_Name"]:
+                        per_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            if not per_kernel:
+                return None
+            # the filter kernel is the one that moves the bytes; drop the small head-of-stream launch of the child
+            name = max(per_kernel, key=lambda k: max(per_kernel[k]))
+            vals = [v for v in per_kernel[name] if v > 0.5 * max(per_kernel[name])]
+            got[ctr] = (sum(vals) / len(vals), len(vals), name.split("(")[0])
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    read_b, write_b = 2.0 * got["FETCH_SIZE"][0] * 1024.0, got["WRITE_SIZE"][0] * 1024.0
+    return {"hbm_bytes_per_launch": read_b + write_b, "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
+            "launches_averaged": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]], "kernel": got["FETCH_SIZE"][2]}
+
+
+def traffic_child(args):
+    """--traffic-child: three passes of the workload's step and nothing else (what live_traffic() profiles)."""
+    pkg = graft.load_pkg()
+    fir = pkg.if_fir
+    taps_n, decim, log2n, _ = WORKLOADS[args.workload]
+    n = 1 << log2n
+    i16 = "_i16_" in args.workload
+    nco = 1638.0 / 8192.0 if "_nco_" in args.workload else 0.0
+    torch.cuda.set_device(0)
+    backend_ids = {"auto": fir.BACKEND_AUTO, "direct": fir.BACKEND_HIP_DIRECT, "fft": fir.BACKEND_HIP_FFT,
+                   "generic": fir.BACKEND_HIP_GENERIC}
+    with fir.IfFir(fir.bpf_design(taps_n), decim, 0, device=0, backend=backend_ids[args.backend]) as f:
+        if nco:
+            f.set_nco(nco)
+        x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+        y = torch.empty(2 * f.out_count(n), dtype=torch.float32, device="cuda")
+        f.synth_device(x.data_ptr(), 0, n, 0)
+        f.synchronize()
+        if i16:
+            f.set_input_format(fir.INPUT_I16)
+            x = torch.clamp(torch.round(x * 16384.0), -32768, 32767).to(torch.int16)
+            torch.cuda.synchronize()
+        for _ in range(3):
+            f.process_device(x.data_ptr(), y.data_ptr(), n)
+        f.synchronize()
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -387,6 +458,10 @@ def main():
                     help="rehearse the launch path on the CPU (gloo, a sleep instead of the filter); no GPU needed")
     ap.add_argument("--condition-ms", type=float, default=300.0,
                     help="device time of untimed GPU work ahead of the warm-up steps (settled power state; see main)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child passes ahead of the "
+                         "benchmark); the committed counter passes of profiles/traffic.json are quoted instead")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the other single-GPU BASELINE configs timed after the headline (extra.configs)")
     args = ap.parse_args()
@@ -403,6 +478,16 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if args.dry_run:
         return dry_run(args, rank, world, json_fd)
+    if args.traffic_child:
+        return traffic_child(args)
+    # roofline.traffic measured on THIS box in THIS run: profiler passes of a short child run, before
+    # this process touches the GPU.  One GPU only (the children use device 0); any failure falls back to the committed passes.
+    live = None
+    if world == 1 and not args.no_live_traffic and not args.channels and args.variant is None:
+        try:
+            live = live_traffic(args.workload, args.backend)
+        except Exception:   # noqa: BLE001 - never fatal
+            live = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libif_fir has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -711,18 +796,20 @@ def main():
         achieved_gbs = bytes_per_launch / (dev_ms_max * 1e-3) / 1e9
         achieved_tf = flops_per_launch / (dev_ms_max * 1e-3) / 1e12
         traffic = traffic_src = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                key = args.workload + (":fir_fft" if f.get_backend() == fir.BACKEND_HIP_FFT else ":fir_direct")
-                rec = json.load(open(tpath)).get(key, {})
+        if live is not None:
+            traffic = live["hbm_bytes_per_launch"]
+            traffic_src = ("measured in this run on this box: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (one counter "
+                           "per pass) of a 3-step child run ahead of the benchmark, kernel %s, %d + %d launches; read bytes = "
+                           "2 x FETCH_SIZE (gfx950 note of MI355X_MICROARCH.md): %.4g GB read + %.4g GB written"
+                           % (live["kernel"], live["launches_averaged"][0], live["launches_averaged"][1],
+                              live["read_bytes_per_launch"] / 1e9, live["write_bytes_per_launch"] / 1e9))
+        else:
+            rec = committed_traffic(args.workload, names[f.get_backend()])
+            if rec and rec.get("hbm_bytes_per_launch") is not None:
                 traffic = rec.get("hbm_bytes_per_launch")
-                if traffic is not None:
-                    traffic_src = ("NOT measured in this run: TCC counters of kernel %s from the committed rocprofv3 "
-                                   "passes profiles/%s_* (another box), file profiles/traffic.json"
-                                   % (rec.get("kernel"), rec.get("round")))
-            except Exception:
-                traffic = None
+                traffic_src = ("NOT measured in this run: TCC counters of kernel %s from the committed rocprofv3 "
+                               "passes profiles/%s_* (another box), file profiles/traffic.json"
+                               % (rec.get("kernel"), rec.get("round")))
         # parity spot check (oracle as checker only): first 4096 outputs of this rank's last step vs the order model.
         # the stream was continued for warmup+steps calls, so regenerate the expected state cheaply: only check that
         # a fresh context reproduces the oracle on the head of the stream.
@@ -766,6 +853,7 @@ def main():
                                      "of the same step) so that the timed steps run in the settled power state"},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_over_algorithmic": round(traffic / bytes_per_launch, 4) if traffic else None,
                          "traffic_source": traffic_src,
                          "kernel_ms": round(dev_ms_max, 4),
                          "cold_kernel_ms": round(cold_ms_max, 4) if cold_ms is not None else None,

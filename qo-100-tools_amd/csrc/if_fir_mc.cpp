@@ -768,9 +768,9 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
         for (unsigned spins = 0;; spins++)
         {
             const hipError_t q = hipStreamQuery(st);
-            if (q != hipErrorNotReady)
+            if (q != hipErrorNotReady && spins > 0)
                 return q;
-            if ((spins & 63u) == 63u)
+            if ((spins & 63u) == 0u) // (also once before the first query result is taken: a reported error is never missed)
             {
                 ncclResult_t ar = ncclSuccess;
                 if (ctx->api->CommGetAsyncError && ctx->comm &&

@@ -13,6 +13,7 @@
 
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -197,6 +198,16 @@ FAKE_API ncclResult_t ncclSend(const void *buf, size_t count, ncclDataType_t typ
 FAKE_API ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t type, int peer, Comm *comm, hipStream_t stream)
 {
     return post(false, buf, count, type, peer, comm, stream);
+}
+// asynchronous error state: healthy, unless the test asks one rank to report a failure (FAKE_RCCL_ASYNC_ERROR_RANK=r): lets
+// the tests reach the library's polling wait without breaking anything
+FAKE_API ncclResult_t ncclCommGetAsyncError(Comm *comm, ncclResult_t *err)
+{
+    if (!comm || !err)
+        return ncclInvalidArgument;
+    const char *e = getenv("FAKE_RCCL_ASYNC_ERROR_RANK");
+    *err = (e && *e && atoi(e) == comm->rank) ? ncclSystemError : ncclSuccess;
+    return ncclSuccess;
 }
 FAKE_API const char *ncclGetErrorString(ncclResult_t r)
 {

@@ -13,6 +13,9 @@ fake, world, channels = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 mode = sys.argv[4] if len(sys.argv) > 4 else ""
 inject = mode == "inject"       # rank 1's first channel fails its first filter call (development library: test hook)
 offphase = mode.startswith("offphase")   # "offphase<D>": call lengths that leave the decimation phase != 0
+asyncerr = mode == "asyncerr"   # rank 1's communicator reports an asynchronous error (stand-in transport hook)
+if asyncerr:
+    os.environ["FAKE_RCCL_ASYNC_ERROR_RANK"] = "1"
 os.environ["IF_FIR_RCCL_LIBRARY"] = fake
 os.environ["IF_FIR_DEBUG"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -70,6 +73,23 @@ def rank_main(rank):
                     for y in outs[k]:
                         y.zero_() if rank == 0 else None
                 torch.cuda.synchronize()
+            if asyncerr:
+                # the library's waits poll ncclCommGetAsyncError: the rank whose communicator reports an error fails the
+                # call with that message, aborts the communicator and refuses further calls; the others complete
+                barrier.wait()
+                try:
+                    mc.process_device([x.data_ptr() for x in ins[0]] if rank == 0 else None,
+                                      [y.data_ptr() for y in outs[0]] if rank == 0 else None, calls[0])
+                    injected[rank] = "ok"
+                except fir.IfFirError as e:
+                    injected[rank] = str(e)
+                if rank == 1:
+                    try:
+                        mc.process_device(None, None, calls[0])
+                        injected["again"] = "ok"
+                    except fir.IfFirError as e:
+                        injected["again"] = str(e)
+                return
             for k, n in enumerate(calls):
                 barrier.wait()
                 m = mc.process_device([x.data_ptr() for x in ins[k]] if rank == 0 else None,
@@ -95,6 +115,12 @@ if errors:
     print("FAIL:", "; ".join(errors))
     sys.exit(1)
 ok = True
+if asyncerr:
+    print("asynchronous error:", injected)
+    good = ("asynchronous error" in injected.get(1, "") and "aborted" in injected.get("again", "")
+            and all(injected.get(r) == "ok" for r in range(world) if r != 1))
+    print("asynchronous error reported by the rank that saw it, communicator aborted, the others completed" if good else "FAIL")
+    sys.exit(0 if good else 1)
 if inject:
     print("injected failure:", injected)
     ok = ("injected failure" in injected.get(1, "") and "rank 1 reported a filter failure" in injected.get(0, "")

@@ -124,7 +124,7 @@ def test_stand_in_transport_builds():
                            os.path.join(root, "tests", "c", "fake_rccl.cpp"), "-o", so])
     syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclSend", "ncclRecv",
-                 "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+                 "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString", "ncclCommGetAsyncError"):
         assert (" T " + name) in syms, name
 
 

@@ -46,3 +46,13 @@ def test_remote_filter_failure_reaches_the_root_and_nobody_hangs(fake_rccl):
                          capture_output=True, text=True, timeout=400)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     assert "injected failure" in run.stdout and "bit-identical" in run.stdout
+
+
+def test_asynchronous_rccl_error_is_reported_not_waited_for(fake_rccl):
+    """the final waits of if_fir_mc_process_device poll ncclCommGetAsyncError instead of blocking.  The stand-in
+    transport makes rank 1's communicator report an error: that rank fails the call with the message, aborts its communicator
+    and refuses further calls; the other ranks complete."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mc_threads_check.py"), fake_rccl, "3", "4", "asyncerr"],
+                         capture_output=True, text=True, timeout=400)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert "communicator aborted, the others completed" in run.stdout
