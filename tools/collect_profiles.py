@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     tag, workload, ktrace, pfetch, pwrite = sys.argv[1:6]
     # the bench line times other configs too (extra.configs): select the headline instantiation by its full name
-    ksub = sys.argv[6] if len(sys.argv) > 6 else "fir_fft_kernel<4, true, false, false, false, false, false>"
+    ksub = sys.argv[6] if len(sys.argv) > 6 else "fir_fft_kernel<4, true, false, false, 0, false, false>"
     key = "fir_fft" if "fir_fft" in ksub else ksub
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     stats = glob.glob(os.path.join(ktrace, "**", "*kernel_stats.csv"), recursive=True)[0]
