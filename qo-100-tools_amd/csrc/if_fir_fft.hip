@@ -693,6 +693,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
             for (int b = 0; b < 4; b++)
             {
+                // a batch none of whose four slots is wanted (e.g. the single-channel decimate-by-16 route: slot 0 only) is
+                // not inverted; its registers are refilled with next-block rows all the same
+                const bool wanted = chan.out[4 * b] || chan.out[4 * b + 1] || chan.out[4 * b + 2] || chan.out[4 * b + 3];
                 cf a[16];
 #pragma unroll
                 for (int i = 0; i < 4; i++)
@@ -709,8 +712,30 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         for (int q = 0; q < 4; q++)
                             load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, 4 * b + q));
                 }
-                cf c[16];
-                inverse_tail256(a, c, twe, xb, lane);
+                if (wanted)
+                {
+                    cf c[16];
+                    inverse_tail256(a, c, twe, xb, lane);
+                    // this lane's channel: buffer and call-constant mix-down phase exp(-j 2 pi s (abs0 + n0) / 16)
+                    float2 *po = cs == 0 ? chan.out[4 * b] : cs == 1 ? chan.out[4 * b + 1] : cs == 2 ? chan.out[4 * b + 2] : chan.out[4 * b + 3];
+                    const cf w0 = {chan.rot0[4 * b][0], chan.rot0[4 * b][1]}, w1 = {chan.rot0[4 * b + 1][0], chan.rot0[4 * b + 1][1]},
+                             w2 = {chan.rot0[4 * b + 2][0], chan.rot0[4 * b + 2][1]}, w3 = {chan.rot0[4 * b + 3][0], chan.rot0[4 * b + 3][1]};
+                    const cf wl = cs == 0 ? w0 : cs == 1 ? w1 : cs == 2 ? w2 : w3;
+                    const int64_t o0 = obase + mu1;
+                    if (po != nullptr && !(diag & 2))
+                    {
+#pragma unroll
+                        for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                        {
+                            const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
+                            if (idx < M)
+                            {
+                                const cf v = cmul_v<false>(c[mu0], wl);
+                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                            }
+                        }
+                    }
+                }
                 if (b >= EARLY_B && next_fast)
                 {
 #pragma unroll
@@ -718,25 +743,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                         for (int q = 0; q < 4; q++)
                             load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, 4 * b + q));
-                }
-                // this lane's channel: buffer and call-constant mix-down phase exp(-j 2 pi s (abs0 + n0) / 16)
-                float2 *po = cs == 0 ? chan.out[4 * b] : cs == 1 ? chan.out[4 * b + 1] : cs == 2 ? chan.out[4 * b + 2] : chan.out[4 * b + 3];
-                const cf w0 = {chan.rot0[4 * b][0], chan.rot0[4 * b][1]}, w1 = {chan.rot0[4 * b + 1][0], chan.rot0[4 * b + 1][1]},
-                         w2 = {chan.rot0[4 * b + 2][0], chan.rot0[4 * b + 2][1]}, w3 = {chan.rot0[4 * b + 3][0], chan.rot0[4 * b + 3][1]};
-                const cf wl = cs == 0 ? w0 : cs == 1 ? w1 : cs == 2 ? w2 : w3;
-                const int64_t o0 = obase + mu1;
-                if (po != nullptr && !(diag & 2))
-                {
-#pragma unroll
-                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                    {
-                        const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
-                        if (idx < M)
-                        {
-                            const cf v = cmul_v<false>(c[mu0], wl);
-                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
-                        }
-                    }
                 }
             }
         }
@@ -768,7 +774,13 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                     for (int ch = 0; ch < 2; ch++)
                     {
-                        const int c = (cp + ch < nch) ? cp + ch : nch - 1; // odd count: the last channel twice, stored once
+                        if (ch == 1 && cp + 1 >= nch) // odd count (or the single-channel decimate-by-8 route): an empty second half
+                        {
+                            a[4 * i + 2] = (cf){0.f, 0.f};
+                            a[4 * i + 3] = (cf){0.f, 0.f};
+                            continue;
+                        }
+                        const int c = cp + ch;
                         const int par = (int)chan.slot[c] & 1;
                         const f2v *g0 = hp + (i * 16 + 8 * par) * 64 + lane;       // k2' = 0: q = s & 1       (+ a * 64 entries)
                         const f2v *g1 = hp + (i * 16 + 8 * (1 - par)) * 64 + lane; // k2' = 1: q = (1 - s) & 1
