@@ -190,12 +190,12 @@ def test_overlap_save_tables_refuse_unsupported(fir):
 
 
 def test_overlap_save_block_queue_hands_out_every_block_once(fir):
-    """The two-level block queue of the overlap-save kernel (host mirror of queue_take() in if_fir_fft.hip): a workgroup's
-    slot s is block s % 8 of its local group s // 8; the first `ahead` local groups are static (global groups b,
-    wgs + b, ...), local group g >= ahead is global group ahead * wgs + ticket, the ticket drawn from the launch's
-    counter by whoever takes slot 0 of local group g - ahead (ahead = 1: a workgroup holds at most one unstarted group).  Whatever the interleaving of the workgroups' takes, every block in [0, nblocks) is
-    handed out exactly once, a wave stops at its first block >= nblocks, and the counter stays below the bound the
-    launcher reports."""
+    """The ARITHMETIC of the two-level block queue (which global group a workgroup's local group g is; the kernel's own
+    queue code runs under test_block_queue_kernel_code_under_host_simulation): a workgroup's slot s is block s % 8 of its
+    local group s // 8; the first `ahead` local groups are static (global groups b, wgs + b, ...), local group g >= ahead is
+    global group ahead * wgs + ticket, the ticket drawn from the launch's counter by whoever takes slot 0 of local group
+    g - ahead.  Whatever the interleaving of the workgroups' takes, every block in [0, nblocks) is handed out exactly once, a
+    wave stops at its first block >= nblocks, and the counter stays below the bound the launcher reports."""
     rng = np.random.default_rng(5)
     sizes = [1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 2047, 2048, 2049, 4369, 8191, 17477, 69871]
     sizes += [int(v) for v in rng.integers(1, 40_000, size=12)]
