@@ -20,7 +20,7 @@ def fake_rccl(gpu_ok):
     return so
 
 
-@pytest.mark.parametrize("world,channels", [(2, 3), (3, 5), (4, 4), (4, 2)])
+@pytest.mark.parametrize("world,channels", [(2, 3), (3, 5), (4, 4), (4, 2), (4, 8)])   # (4, 8): BASELINE configs[3]'s 8 channels x 255 taps
 def test_ranks_as_threads_match_single_channel_contexts(fake_rccl, world, channels):
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mc_threads_check.py"), fake_rccl, str(world), str(channels)],
                          capture_output=True, text=True, timeout=400)
