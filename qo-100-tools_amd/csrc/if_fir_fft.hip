@@ -164,7 +164,8 @@ constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_TWD = 65536 + 20
               LDS_NCO = LDS_TWE + 8192, LDS_XB = LDS_NCO + 512;
 static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 constexpr int LDS_Q = LDS_XB + FFT_WAVES * XBUF; // workgroup block queue: slot counter (16 B) + ring of group entries
-constexpr int FFT_LDS_BYTES = LDS_Q + 16 + Q_RING * 8;
+constexpr int LDS_QPTR = LDS_Q + 16 + Q_RING * 8; // 16-slot bank: the 16 output pointers (kept out of the SGPRs)
+constexpr int FFT_LDS_BYTES = LDS_QPTR + 16 * 8;
 
 __device__ __forceinline__ void exchange1_fwd(cf (&r)[64])
 {
@@ -429,7 +430,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // samples with the second partition's table and adds its result to what the first launch stored
     static_assert(!ACC || (!DEC4 && !CHAN && OVL_ROWS == 32), "accumulating store: full-rate pipeline, 32 overlap rows");
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
-    static_assert(CHAN == 0 || ((CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4 && !NCO), "the filter bank is a decimating variant (4, 8, 16)");
+    static_assert(CHAN == 0 || ((CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4), "the filter bank is a decimating variant (4, 8, 16)");
+    static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
@@ -468,6 +470,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         f4v_t *dst = reinterpret_cast<f4v_t *>(smem);
         for (int i = threadIdx.x; i < LDS_XB / 16; i += 512)
             dst[i] = src[i];
+        if constexpr (CHAN == 16)
+        {
+            if (threadIdx.x < 16)
+                reinterpret_cast<float2 **>(smem + LDS_QPTR)[threadIdx.x] = chan.out[threadIdx.x];
+        }
         // block queue (if_fir_fft_queue.h): the current-group word and the look-ahead ring
         if (threadIdx.x < Q_RING)
             reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16)[threadIdx.x] = queue_ring_init(threadIdx.x, blockIdx.x, gridDim.x);
@@ -667,6 +674,15 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         // outputs beyond M are dropped by the descriptor's bounds check
         const int64_t obase = blk * LOUT;
         const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
+        // filter-bank tails with an NCO: the block's share of the output rotation, phasor(phi0 + delta obase), wave-uniform
+        cf nco_blk = {1.0f, 0.0f};
+        if constexpr (NCO && CHAN != 0)
+        {
+            const float2 pb = nco_phasor(nco_phi0 + nco_delta * (uint32_t)obase);
+            nco_blk = (cf){__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pb.x))),
+                           __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pb.y)))};
+        }
+        (void)nco_blk;
         if constexpr (CHAN == 16)
         {
             // ---- 16-slot filter bank at the channel rate (decimation 16, round 3; tools/fft_model.py bank16) --------------
@@ -690,12 +706,16 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             constexpr int MU0_FIRST = OVL_ROWS / 4;
             constexpr int EARLY_B = I16 ? 3 : 1; // batches whose next-block rows are requested ahead of their inverse (no scratch)
             const int cs = lane & 3, mu1 = lane >> 2;
+            // NCO (a tuned single channel through the one-channel route, or a common fine offset of the whole slot grid):
+            // output m = obase + 16 (mu0 - first) + mu1 is rotated by phasor(phi0 + delta m) = A(lane) * B(mu0 - first), B from
+            // the table (step 16 delta, fft_build_tables)
+            // with A(lane) = [phasor(phi0 + delta obase), wave-uniform, in SGPRs] * [phasor(delta mu1), table entries 32..47]
 #pragma unroll
             for (int b = 0; b < 4; b++)
             {
                 // a batch none of whose four slots is wanted (e.g. the single-channel decimate-by-16 route: slot 0 only) is
                 // not inverted; its registers are refilled with next-block rows all the same
-                const bool wanted = chan.out[4 * b] || chan.out[4 * b + 1] || chan.out[4 * b + 2] || chan.out[4 * b + 3];
+                const bool wanted = ((chan.mask16 >> (4 * b)) & 15u) != 0u;
                 cf a[16];
 #pragma unroll
                 for (int i = 0; i < 4; i++)
@@ -716,11 +736,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
                     cf c[16];
                     inverse_tail256(a, c, twe, xb, lane);
-                    // this lane's channel: buffer and call-constant mix-down phase exp(-j 2 pi s (abs0 + n0) / 16)
-                    float2 *po = cs == 0 ? chan.out[4 * b] : cs == 1 ? chan.out[4 * b + 1] : cs == 2 ? chan.out[4 * b + 2] : chan.out[4 * b + 3];
-                    const cf w0 = {chan.rot0[4 * b][0], chan.rot0[4 * b][1]}, w1 = {chan.rot0[4 * b + 1][0], chan.rot0[4 * b + 1][1]},
-                             w2 = {chan.rot0[4 * b + 2][0], chan.rot0[4 * b + 2][1]}, w3 = {chan.rot0[4 * b + 3][0], chan.rot0[4 * b + 3][1]};
-                    const cf wl = cs == 0 ? w0 : cs == 1 ? w1 : cs == 2 ? w2 : w3;
+                    // this lane's channel: its buffer (pointer table in LDS) and the call-constant mix-down phase
+                    // exp(-j 2 pi s (abs0 + n0) / 16) = W16^(s rot_e) (table entries 16..31: the 16th roots of unity)
+                    float2 *po = reinterpret_cast<float2 *const *>(smem + LDS_QPTR)[4 * b + cs];
+                    cf wl = ncob[16 + (((4 * b + cs) * (int)chan.rot_e) & 15)];
+                    if constexpr (NCO)
+                        wl = cmul_v<false>(cmul_s<false>(wl, nco_blk), ncob[32 + mu1]);
                     const int64_t o0 = obase + mu1;
                     if (po != nullptr && !(diag & 2))
                     {
@@ -730,7 +751,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                             const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
                             if (idx < M)
                             {
-                                const cf v = cmul_v<false>(c[mu0], wl);
+                                cf v;
+                                if constexpr (NCO)
+                                    v = cmul_v<false>(c[mu0], cmul_v<false>(wl, ncob[mu0 - MU0_FIRST]));
+                                else
+                                    v = cmul_v<false>(c[mu0], wl);
                                 __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
                             }
                         }
@@ -820,8 +845,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 float2 *po = chl ? chan.out[c1] : chan.out[cp];
                 const cf r0 = chl ? (cf){chan.rot0[c1][0], chan.rot0[c1][1]} : (cf){chan.rot0[cp][0], chan.rot0[cp][1]};
                 const int sl = chl ? (int)chan.slot[c1] : (int)chan.slot[cp];
-                const cf wl = ((sl & lane) & 1) ? (cf){-r0.x, -r0.y} : r0;
+                cf wl = ((sl & lane) & 1) ? (cf){-r0.x, -r0.y} : r0;
                 const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
+                if constexpr (NCO) // as in the 16-slot tail: phasor(phi0 + delta m) = [block, uniform] * [lane: entries 32..63] * B(mu0 - first)
+                    wl = cmul_v<false>(cmul_s<false>(wl, nco_blk), ncob[32 + 2 * (lane >> 2) + (lane & 1)]);
                 if (cl < nch && !(diag & 2))
                 {
 #pragma unroll
@@ -830,7 +857,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
                         if (idx < M)
                         {
-                            const cf v = cmul_v<false>(c[mu0], wl);
+                            cf v;
+                            if constexpr (NCO)
+                                v = cmul_v<false>(c[mu0], cmul_v<false>(wl, ncob[mu0 - MU0_FIRST]));
+                            else
+                                v = cmul_v<false>(c[mu0], wl);
                             __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
                         }
                     }
@@ -1201,12 +1232,26 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
 {
     if (a.chan)
     {
-        if ((a.D != 4 && a.D != 8 && a.D != 16) || a.nco_word || a.ctaps || a.chan->count < 1 || a.chan->count > CHAN_MAX)
+        if ((a.D != 4 && a.D != 8 && a.D != 16) || a.chan->count < 1 || a.chan->count > CHAN_MAX ||
+            (a.D == 4 && (a.nco_word || a.ctaps)))
             return hipErrorInvalidConfiguration;
+        const int ckey = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
         if (a.D == 8) // per channel (pairs share a small inverse); chan->tw[] = W16^(a slot), a = 1..7
-            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 8>(a) : launch_fft_t<ROWS, true, false, false, 8>(a);
+            switch (ckey)
+            {
+            case 0: return launch_fft_t<ROWS, true, false, false, 8>(a);
+            case 1: return launch_fft_t<ROWS, true, false, true, 8>(a);
+            case 2: return launch_fft_t<ROWS, true, true, false, 8>(a);
+            default: return launch_fft_t<ROWS, true, true, true, 8>(a);
+            }
         if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
-            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 16>(a) : launch_fft_t<ROWS, true, false, false, 16>(a);
+            switch (ckey)
+            {
+            case 0: return launch_fft_t<ROWS, true, false, false, 16>(a);
+            case 1: return launch_fft_t<ROWS, true, false, true, 16>(a);
+            case 2: return launch_fft_t<ROWS, true, true, false, 16>(a);
+            default: return launch_fft_t<ROWS, true, true, true, 16>(a);
+            }
         return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 4>(a) : launch_fft_t<ROWS, true, false, false, 4>(a);
     }
     const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
@@ -1317,9 +1362,14 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
     float *tw1 = tables, *hp = tables + 2 * 4096, *tw2 = tables + 4 * 4096;
     float *twd = tw2 + 2 * 256, *twe = twd + 2 * 1024, *ncob = twe + 2 * 1024;
     // NCO (SPEC §3.2): rotation shared by the 64 outputs of row r of a block, exp(+j*2*pi*((64 r delta) mod 2^32)/2^32)
+    // (the decimating filter-bank tails store 16 / 32 outputs per slot: bank = 16 / 8)
+    const uint32_t nco_step = bank == 16 ? 16u : bank == 8 ? 32u : 64u;
     for (uint32_t r = 0; r < 64; r++)
     {
-        const uint32_t ph = 64u * r * nco_delta;
+        // (bank tails: entries 32..63 hold the lane's share, phasor((r - 32) delta): output index within a slot; entries
+        // 16..31 the 16th roots of unity W16^(r - 16) = exp(-j 2 pi (r - 16) / 16): the slots' mix-down phases)
+        const uint32_t ph = (bank && r >= 32) ? (r - 32u) * nco_delta
+                            : (bank && r >= 16) ? 0u - ((r - 16u) << 28) : nco_step * r * nco_delta;
         const double a = PI2 * ((double)ph / 4294967296.0);
         ncob[2 * r + 0] = (float)cos(a);
         ncob[2 * r + 1] = (float)sin(a);

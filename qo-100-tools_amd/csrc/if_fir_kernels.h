@@ -26,6 +26,8 @@ struct ChanArgs
     float tw[CHAN_MAX][14];  // decimation 4: W16^(m0 slot), m0 = 1..3 (re, im); decimation 8: W16^(a slot), a = 1..7
     float rot0[CHAN_MAX][2]; // exp(-j 2 pi slot (abs0 + n0) / 16): mix-down phase at this call's first output
     float2 *out[CHAN_MAX];   // device, M samples each
+    uint32_t mask16;         // decimation 16: bit s set = slot s is wanted (out[s] non-null)
+    uint32_t rot_e;          // decimation 16: (abs0 + n0) mod 16: slot s is rotated by W16^(s rot_e) at this call's first output
 };
 
 struct LaunchArgs

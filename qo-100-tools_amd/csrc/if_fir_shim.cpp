@@ -83,13 +83,13 @@ static void set_err(const if_fir_ctx *ctx, const char *fmt, ...)
 static inline int eff_ctaps(const if_fir_ctx *ctx) { return ctx->ctaps || ctx->nco_word; }
 static inline const float *eff_taps(const if_fir_ctx *ctx) { return ctx->h_eff ? ctx->h_eff : ctx->h_taps; }
 
-// Decimation 8 and 16 with real taps and no NCO run as a ONE-channel filter bank at slot 0 on the overlap-save backend (round 3):
-// the alias fold happens in the frequency domain and a 512- / 256-point inverse replaces the full-rate inverse + selecting
-// store (≈ 1.8 k instead of 2.9 k VALU instructions per block).  Complex taps, an NCO, two-partition filters and every other
-// decimation keep the selecting store.
+// Decimation 8 and 16 run as a ONE-channel filter bank at slot 0 on the overlap-save backend (round 3): the alias fold happens
+// in the frequency domain and a 512- / 256-point inverse replaces the full-rate inverse + selecting store (≈ 1.8 k instead of
+// 2.9 k VALU instructions per block).  Real or complex taps, with or without the NCO (the tuned-and-decimated channel of an
+// SDR); two-partition filters and every other decimation keep the selecting store.
 static inline bool bank_route(const if_fir_ctx *ctx)
 {
-    return (ctx->D == 8 || ctx->D == 16) && !eff_ctaps(ctx) && !if_fir::fft_two_partitions(ctx->T) && ctx->variant != 3000;
+    return (ctx->D == 8 || ctx->D == 16) && !if_fir::fft_two_partitions(ctx->T) && ctx->variant != 3000;
 }
 
 // AUTO: the fastest backend that meets SPEC §3.  Measured over (taps, decimation) from 3 taps to 4095 and decimation
@@ -190,7 +190,7 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
     return 1;
 }
 
-// merged table image of the filter bank at decimation 8 or 16 (real taps, no NCO)
+// merged table image of the filter bank at decimation 8 or 16
 static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
 {
     if (ctx->d_fft_tables_bank)
@@ -201,7 +201,9 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
         set_err(ctx, "filter-bank tables: out of host memory");
         return 0;
     }
-    if_fir::fft_build_tables(ctx->h_taps, ctx->T, 0, ctx->D, 0u, ctx->in_i16 ? 0x1p-15 : 1.0, tab, ctx->D);
+    // (the NCO's effective complex taps and its per-output phase step, like the single-channel tables)
+    if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)ctx->D,
+                             ctx->in_i16 ? 0x1p-15 : 1.0, tab, ctx->D);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables_bank, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
@@ -607,6 +609,13 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
             chan->rot0[c][0] = (float)cos(-2.0 * M_PI * (double)e / 16.0);
             chan->rot0[c][1] = (float)sin(-2.0 * M_PI * (double)e / 16.0);
         }
+        if (ctx->D == 16)
+        {
+            chan->rot_e = (uint32_t)((ctx->consumed + n0) & 15u);
+            chan->mask16 = 0;
+            for (uint32_t c = 0; c < 16; c++)
+                chan->mask16 |= chan->out[c] ? (1u << c) : 0u;
+        }
         a.chan = chan;
         if (ctx->D == 16 || ctx->D == 8)
             a.fft_tables = ctx->d_fft_tables_bank;
@@ -663,10 +672,10 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
         set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot and output arrays", if_fir::CHAN_MAX);
         return 0;
     }
-    if ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || pCtx->ctaps || pCtx->nco_word ||
+    if ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || (pCtx->D == 4 && (pCtx->ctaps || pCtx->nco_word)) ||
         !if_fir::fft_supported(pCtx->T, pCtx->D) || if_fir::fft_two_partitions(pCtx->T))
     {
-        set_err(pCtx, "if_fir_channelizer_process_device: needs real taps (<= 3073), decimation 4, 8 or 16, no NCO");
+        set_err(pCtx, "if_fir_channelizer_process_device: needs <= 3073 taps and decimation 4 (real taps, no NCO), 8 or 16");
         return 0;
     }
     if (pCtx->backend != IF_FIR_BACKEND_HIP_FFT)
@@ -1134,6 +1143,11 @@ IF_FIR_API uint8_t if_fir_set_nco(if_fir_ctx_t *pCtx, double dFreq)
     {
         (void)hipFree(pCtx->d_fft_tables);
         pCtx->d_fft_tables = nullptr;
+    }
+    if (pCtx->d_fft_tables_bank)
+    {
+        (void)hipFree(pCtx->d_fft_tables_bank);
+        pCtx->d_fft_tables_bank = nullptr;
     }
     pCtx->backend = b;
     if (b == IF_FIR_BACKEND_HIP_FFT && !ensure_fft_tables(pCtx))

@@ -720,7 +720,7 @@ def test_uniform_filter_bank(fir, oracle, torch_cuda, t):
             f.channelizer_process_device([16], xd.data_ptr(), [xd.data_ptr()], 16)
         f.set_nco(0.1)
         with pytest.raises(fir.IfFirError, match="no NCO"):
-            f.channelizer_process_device([1], xd.data_ptr(), [xd.data_ptr()], 16)
+            f.channelizer_process_device([1], xd.data_ptr(), [xd.data_ptr()], 16)   # (decimation 4 only: 8 / 16 take one)
     with fir.IfFir(taps, 1, 0) as f:
         with pytest.raises(fir.IfFirError, match="decimation 4"):
             f.channelizer_process_device([1], xd.data_ptr(), [xd.data_ptr()], 16)
@@ -783,6 +783,51 @@ def test_filter_bank_at_decimation_8_and_16(fir, oracle, torch_cuda, d, t, i16):
         if d == 16:
             with pytest.raises(fir.IfFirError, match="twice"):
                 f.channelizer_process_device([3, 3], xd.data_ptr(), [xd.data_ptr(), xd.data_ptr()], 16)
+
+
+@pytest.mark.parametrize("d,i16", [(16, False), (8, False), (16, True), (8, True)])
+def test_filter_bank_with_a_common_fine_offset(fir, oracle, torch_cuda, d, i16):
+    """The context's NCO shifts the whole fs/16 slot grid (decimation 8 and 16): channel c is centred at slot/16 + f_nco.
+    Every channel against the float64 NCO oracle at that frequency, ragged pieces."""
+    torch = torch_cuda
+    taps = fir.bpf_design(255, 0.0, 0.02)
+    n = 200_007
+    f0 = 0.0123
+    if i16:
+        xi = np.clip(np.round(oracle.synth_iq(n, 53) * 12000.0), -32768, 32767).astype(np.int16)
+        x = xi.astype(np.float32) * np.float32(2.0 ** -15)
+        xd = torch.from_numpy(xi).cuda()
+        cuts = [0, 4, 50_004, n]
+    else:
+        x = oracle.synth_iq(n, 53)
+        xd = torch.from_numpy(x).cuda()
+        cuts = [0, 1, 40_001, 40_018, n]
+    slots = [0, 5, 9, 15, 2] if d == 8 else [0, 5, 9, 15, 2, 12]
+    with fir.IfFir(taps, d, n) as f:
+        if i16:
+            f.set_input_format(fir.INPUT_I16)
+        f.set_nco(f0)
+        word = oracle.nco_phase_word(f.get_nco())
+        parts = [[] for _ in slots]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            m_exp = oracle.out_count(a, b - a, d)
+            outs = [torch.full((2 * m_exp + 8,), 3.0, dtype=torch.float32, device="cuda") for _ in slots]
+            piece = xd[2 * a:2 * b].clone()
+            torch.cuda.synchronize()
+            assert f.channelizer_process_device(slots, piece.data_ptr(), [o.data_ptr() for o in outs], b - a) == m_exp
+            f.synchronize()
+            for c in range(len(slots)):
+                o = outs[c].cpu().numpy()
+                assert np.all(o[2 * m_exp:] == 3.0)
+                parts[c].append(o[:2 * m_exp])
+        for c, sl in enumerate(slots):
+            ref = oracle.fir_nco_f64(taps, x, d, ((sl << 28) + word) & 0xFFFFFFFF)
+            l2, mx = oracle.err_metrics(np.concatenate(parts[c]), ref)
+            assert l2 <= TOL and mx <= TOL, (d, i16, sl, l2, mx)
+    with fir.IfFir(taps, 4, n) as f:
+        f.set_nco(f0)
+        with pytest.raises(fir.IfFirError, match="decimation 4"):
+            f.channelizer_process_device([1], xd.data_ptr(), [xd.data_ptr()], 16)
 
 
 def test_random_configurations_against_the_oracle(fir, oracle):
@@ -897,8 +942,14 @@ def test_fft_backend_any_decimation(fir, oracle, t, d):
         f.set_tuning(0)
         f.reset()
         f.set_nco(0.137)
-        l2, mx = oracle.err_metrics(f.process(x), oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(0.137)))
+        ref_nco = oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(0.137))
+        l2, mx = oracle.err_metrics(f.process(x), ref_nco)
         assert l2 <= TOL and mx <= TOL, ("nco", l2, mx)
+        f.reset()       # the NCO through ragged pieces too (decimation 8 / 16: the one-channel filter-bank route with its
+        cuts = [0, 3, d + 1, 3842 + d, 50_001, n]   # output rotation split into block, lane and slot factors)
+        yp = np.concatenate([f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        l2, mx = oracle.err_metrics(yp, ref_nco)
+        assert l2 <= TOL and mx <= TOL, ("nco ragged", l2, mx)
     xi = np.clip(np.round(x * 6000.0), -32768, 32767).astype(np.int16)
     xf = xi.astype(np.float32) * np.float32(2.0 ** -15)
     with fir.IfFir(taps, d, n) as f:
