@@ -161,6 +161,39 @@ int main(void)
         CHECK(if_fir_dev_free(pFir, pDevIn), "free");
     }
     if_fir_destroy(pFir);
+    pFir = NULL;
+
+    /* 6. the bank at the channel rate: decimation 16, all 16 slots from one forward transform, three of them wanted */
+    {
+        enum { DECIM16 = 16 };
+        const uint32_t aulSlots[3] = {1, 8, 15};
+        const uint64_t ullOut16 = (SAMPLES + DECIM16 - 1) / DECIM16;
+        void *pDevIn = NULL, *apDevOut[3] = {NULL, NULL, NULL};
+
+        CHECK(if_bpf_design(pfTaps, TAPS, 0.0, 0.02, IF_BPF_WINDOW_BLACKMAN), "prototype design");
+        CHECK(if_fir_init(&pFir, pfTaps, TAPS, DECIM16, SAMPLES, 0), "init (decimation 16): %s", if_fir_last_error(NULL));
+        CHECK(if_fir_dev_alloc(pFir, &pDevIn, 8 * SAMPLES) && if_fir_dev_upload(pFir, pDevIn, pfX, 8 * SAMPLES), "device input");
+        for(uint32_t c = 0; c < 3; c++)
+            CHECK(if_fir_dev_alloc(pFir, &apDevOut[c], 8 * (ullOut16 + 2)), "device output");
+        CHECK(if_fir_channelizer_process_device(pFir, 3, aulSlots, pDevIn, apDevOut, SAMPLES, &ullOut) && ullOut == ullOut16,
+              "filter bank at decimation 16: %s", if_fir_last_error(pFir));
+        CHECK(if_fir_synchronize(pFir), "synchronize");
+        for(uint32_t c = 0; c < 3; c++)
+        {
+            reference(pfTaps, TAPS, DECIM16, aulSlots[c] << 28, pfX, SAMPLES, pdRef);
+            CHECK(if_fir_dev_download(pFir, pfY, apDevOut[c], 8 * ullOut), "download");
+            CHECK(max_rel_err(pfY, pdRef, 2 * ullOut) <= 1e-6, "filter bank (16) slot %u error %g", aulSlots[c],
+                  max_rel_err(pfY, pdRef, 2 * ullOut));
+            CHECK(if_fir_dev_free(pFir, apDevOut[c]), "free");
+        }
+        /* and one tuned, decimated channel the ordinary way: NCO + decimate-by-16 through if_fir_process */
+        CHECK(if_fir_reset(pFir) && if_fir_set_nco(pFir, 0.1371) && if_fir_get_nco(pFir, &dFreq), "NCO: %s", if_fir_last_error(pFir));
+        reference(pfTaps, TAPS, DECIM16, (uint32_t)(int64_t)llround(dFreq * 4294967296.0), pfX, SAMPLES, pdRef);
+        CHECK(if_fir_process(pFir, pfX, pfY, SAMPLES, &ullOut) && ullOut == ullOut16, "NCO + decimate-by-16");
+        CHECK(max_rel_err(pfY, pdRef, 2 * ullOut) <= 1e-6, "NCO + decimate-by-16 error %g", max_rel_err(pfY, pdRef, 2 * ullOut));
+        CHECK(if_fir_dev_free(pFir, pDevIn), "free");
+    }
+    if_fir_destroy(pFir);
     printf("if_fir_selftest: all checks passed\n");
     return 0;
 }
