@@ -36,7 +36,7 @@ uint8_t if_fir_time_device(if_fir_ctx_t *pCtx, const void *pDevIn, void *pDevOut
 uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulWords);
 /* host-only: the overlap-save kernel's table image (float32, ulOutFloats >= IF_FIR_DEBUG_TABLE_FLOATS) for these taps;
  * returns the number of floats written, 0 if the (taps, decimation) pair is not served by that kernel. */
-#define IF_FIR_DEBUG_TABLE_FLOATS 21120u
+#define IF_FIR_DEBUG_TABLE_FLOATS 21632u
 uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
                                  uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats);
 /* host-only: block-queue layout of an overlap-save launch: pllOut[6] = blocks per group, groups, static groups per

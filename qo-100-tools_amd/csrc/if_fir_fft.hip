@@ -161,7 +161,7 @@ constexpr int XBUF = 4 * XREG;        // per-wave exchange buffer
 constexpr int FFT_WAVES = 8;
 static_assert(FFT_WAVES == (int)QB, "one slot of a block group per wave of the workgroup");
 constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_TWD = 65536 + 2048, LDS_TWE = LDS_TWD + 8192,
-              LDS_NCO = LDS_TWE + 8192, LDS_XB = LDS_NCO + 512;
+              LDS_NCO = LDS_TWE + 8192, LDS_TWF = LDS_NCO + 512, LDS_XB = LDS_TWF + 2048;
 static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 constexpr int LDS_Q = LDS_XB + FFT_WAVES * XBUF; // workgroup block queue: slot counter (16 B) + ring of group entries
 constexpr int LDS_QPTR = LDS_Q + 16 + Q_RING * 8; // 16-slot bank: the 16 output pointers (kept out of the SGPRs)
@@ -364,6 +364,25 @@ struct DevQueue
     __device__ __forceinline__ unsigned wgs() const { return gridDim.x; }
 };
 
+// 8-point inverse DFT (unnormalised), natural order in and out: two 4-point butterflies + W8 twiddles
+__device__ __forceinline__ void ifft8(cf (&v)[8])
+{
+    constexpr float R = 0.70710678118654752f;
+    cf e[4], o[4];
+    bfly4<true>(v[0], v[2], v[4], v[6], e[0], e[1], e[2], e[3]);
+    bfly4<true>(v[1], v[3], v[5], v[7], o[0], o[1], o[2], o[3]);
+    o[1] = cmul_s<false>(o[1], (cf){R, R});   // exp(+j pi / 4)
+    o[3] = cmul_s<false>(o[3], (cf){-R, R});  // exp(+j 3 pi / 4)
+    v[0] = e[0] + o[0];
+    v[4] = e[0] - o[0];
+    v[1] = e[1] + o[1];
+    v[5] = e[1] - o[1];
+    v[2] = add_rot<true>(e[2], o[2]);         // e + j o
+    v[6] = sub_rot<true>(e[2], o[2]);
+    v[3] = e[3] + o[3];
+    v[7] = e[3] - o[3];
+}
+
 // common tail of the small inverses: a[j], j = 4 i + low (low = mu2 of the 1024-point inverse, or the channel-in-batch of the
 // 16-slot bank), k0 = 4 g + i, k1 = lane % 16:
 //   X: row transposition (one round of exchange 2): element j of lane (g, k1) -> lane (g, j), slot k1; iFFT16 over k1 -> mu1
@@ -430,14 +449,16 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // samples with the second partition's table and adds its result to what the first launch stored
     static_assert(!ACC || (!DEC4 && !CHAN && OVL_ROWS == 32), "accumulating store: full-rate pipeline, 32 overlap rows");
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
-    static_assert(CHAN == 0 || ((CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4), "the filter bank is a decimating variant (4, 8, 16)");
+    // CHAN names the decimating tail beyond the plain decimate-by-4 one: 2 = single channel, decimation 2 (frequency-domain
+    // fold + 2048-point inverse); 4 / 8 / 16 = the filter bank at that decimation
+    static_assert(CHAN == 0 || ((CHAN == 2 || CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4), "decimating tails: 2, or the bank at 4, 8, 16");
     static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
     const char *in = reinterpret_cast<const char *>(in_);
     constexpr int L = FFT_N - OVL;         // new input samples per block
-    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : DEC4 ? L / 4 : L; // outputs per block (per channel)
+    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : CHAN == 2 ? L / 2 : DEC4 ? L / 4 : L; // outputs per block (per channel)
     constexpr int EARLY_GROUPS = IF_FIR_FFT_EARLY_GROUPS; // dec4: batches of next-block loads issued during pass 3
     constexpr int LAUX = IF_FIR_FFT_LOAD_AUX(OVL_ROWS); // cache policy of the row loads
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -513,6 +534,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     const f2v *tw2 = reinterpret_cast<const f2v *>(smem + LDS_TW2);
     const f2v *twd = reinterpret_cast<const f2v *>(smem + LDS_TWD);
     const f2v *twe = reinterpret_cast<const f2v *>(smem + LDS_TWE);
+    const f2v *twf = reinterpret_cast<const f2v *>(smem + LDS_TWF);  // decimate-by-2 inverse: W2048^(16 k1 + k0)
+    (void)twf;
     const f2v *ncob = reinterpret_cast<const f2v *>(smem + LDS_NCO); // NCO: phasor of output row r of a block
     (void)ncob;
     char *xb = smem + LDS_XB + wid * XBUF;
@@ -769,6 +792,102 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         for (int q = 0; q < 4; q++)
                             load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, 4 * b + q));
                 }
+            }
+        }
+        else if constexpr (CHAN == 2)
+        {
+            // ---- decimate-by-2 tail (round 3; tools/fft_model.py inverse_dec2): pass 3, multiply by H/4096, fold the 2 aliases
+            // (k2 = k2' + 8 j) in place: r[phys(i, k2')] = z(i, k2'), k2' = 0..7; the other 8 registers of the group are dead
+            // and refilled with rows of the next block right away
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                cf t[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    t[j] = r[phys(i, j)];
+                fft16<false>(t);
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    t[j] = cmul_v<false>(t[j], hp[(i * 16 + j) * 64 + lane]);
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    r[phys(i, j)] = t[j] + t[j + 8];
+                if (next_fast)
+                {
+#pragma unroll
+                    for (int j = 8; j < 16; j++)
+                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                }
+            }
+            // 2048-point inverse (8 x 16 x 16): 8-point inverse over k2' -> mu2, twiddle conj W2048^((16 k1 + k0) mu2) =
+            // conj(W2048^x)^(mu2 & 1) * conj(W1024^(x (mu2 >> 1))), then the common tail twice (hb = mu2 >> 2, low = mu2 & 3):
+            // lane = 4 mu1 + low, slot mu0 -> y_D[128 mu0 + 8 mu1 + 4 hb + low]
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                cf z[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    z[j] = r[phys(i, j)];
+                ifft8(z);
+                const f2v wf = twf[i * 64 + lane];
+#pragma unroll
+                for (int mu2 = 1; mu2 < 8; mu2++)
+                {
+                    if (mu2 & 1)
+                        z[mu2] = cmul_v<true>(z[mu2], wf);
+                    if (mu2 >> 1)
+                        z[mu2] = cmul_v<true>(z[mu2], twd[(i * 4 + (mu2 >> 1)) * 64 + lane]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    r[phys(i, j)] = z[j];
+            }
+            constexpr int MU0_FIRST = OVL_ROWS / 4; // 128 decimated outputs per mu0 slot = 256 input samples = 4 rows
+            cf a_lane = {1.0f, 0.0f}, hb_step = {1.0f, 0.0f};
+            if constexpr (NCO)
+            {
+                // output m = obase + 128 (mu0 - first) + 8 mu1 + 4 hb + low is rotated by phasor(phi0 + delta m): a lane
+                // factor, a wave-uniform factor for hb = 1 and the row table (its entries are 64 full-rate rows apart = 32
+                // decimated outputs: slot k of this tail is entry 4 k)
+                const float2 pa = nco_phasor(nco_phi0 + nco_delta * ((uint32_t)obase + 8u * (uint32_t)(lane >> 2) + (uint32_t)(lane & 3)));
+                a_lane = (cf){pa.x, pa.y};
+                const float2 ph = nco_phasor(4u * nco_delta);
+                hb_step = (cf){__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ph.x))),
+                               __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ph.y)))};
+            }
+            (void)a_lane; (void)hb_step;
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++)
+            {
+                cf a[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        a[4 * i + q] = r[phys(i, 4 * hb + q)];
+                if (hb == 1 && next_fast) // the last 32 registers are free now: the rest of the next block's rows
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                }
+                cf c[16];
+                inverse_tail256(a, c, twe, xb, lane);
+                if constexpr (NCO)
+                {
+                    const cf al = hb ? cmul_s<false>(a_lane, hb_step) : a_lane;
+#pragma unroll
+                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                        c[mu0] = cmul_v<false>(c[mu0], cmul_v<false>(al, ncob[4 * (mu0 - MU0_FIRST)]));
+                }
+                const unsigned vo = (8u * (unsigned)(lane >> 2) + 4u * hb + (unsigned)(lane & 3)) * 8u;
+#pragma unroll
+                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    buf_store(osrd, vo, (mu0 - MU0_FIRST) * 1024, c[mu0]);
             }
         }
         else if constexpr (CHAN == 8)
@@ -1156,7 +1275,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 {
     auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN, ACC>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
-    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : DEC4 ? L / 4 : L;
+    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : CHAN == 2 ? L / 2 : DEC4 ? L / 4 : L;
     static DeviceSetup setup;
     int ncus = 0;
     {
@@ -1255,6 +1374,14 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
         return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 4>(a) : launch_fft_t<ROWS, true, false, false, 4>(a);
     }
     const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
+    if (a.D == 2 && !a.no_fold) // frequency-domain fold + 2048-point inverse (round 3)
+        switch (key)
+        {
+        case 0: return launch_fft_t<ROWS, true, false, false, 2>(a);
+        case 1: return launch_fft_t<ROWS, true, false, true, 2>(a);
+        case 2: return launch_fft_t<ROWS, true, true, false, 2>(a);
+        default: return launch_fft_t<ROWS, true, true, true, 2>(a);
+        }
     if (a.D == 4)
         switch (key)
         {
@@ -1360,7 +1487,16 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
 {
     const double PI2 = 6.283185307179586476925286766559;
     float *tw1 = tables, *hp = tables + 2 * 4096, *tw2 = tables + 4 * 4096;
-    float *twd = tw2 + 2 * 256, *twe = twd + 2 * 1024, *ncob = twe + 2 * 1024;
+    float *twd = tw2 + 2 * 256, *twe = twd + 2 * 1024, *ncob = twe + 2 * 1024, *twf = ncob + 2 * 64;
+    // decimate-by-2 inverse: twf[i*64 + lane] = W2048^(16*(lane%16) + 4*(lane/16) + i)
+    for (int i = 0; i < 4; i++)
+        for (int lane = 0; lane < 64; lane++)
+        {
+            const int e = 16 * (lane % 16) + 4 * (lane / 16) + i;
+            const double a = -PI2 * (double)e / 2048.0;
+            twf[2 * (i * 64 + lane) + 0] = (float)cos(a);
+            twf[2 * (i * 64 + lane) + 1] = (float)sin(a);
+        }
     // NCO (SPEC §3.2): rotation shared by the 64 outputs of row r of a block, exp(+j*2*pi*((64 r delta) mod 2^32)/2^32)
     // (the decimating filter-bank tails store 16 / 32 outputs per slot: bank = 16 / 8)
     const uint32_t nco_step = bank == 16 ? 16u : bank == 8 ? 32u : 64u;

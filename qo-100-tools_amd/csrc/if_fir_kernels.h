@@ -60,6 +60,7 @@ struct LaunchArgs
                           // itself; nullptr = the caller runs launch_history (all other backends, or no outputs)
     uint32_t *queue_base; // host: which of the two counters in `queue` the next overlap-save launch draws from (each
     bool *queue_valid;    //       launch zeroes the other one); *queue_valid = false after anybody else touched them
+    int no_fold;          // development: decimation 2 through the selecting store instead of the frequency-domain fold
     const ChanArgs *chan; // filter-bank launch (overlap-save backend, D = 4 or 16): `out` is unused, outputs go to chan->out[]
                           // (D = 16: all 16 slots are computed; out[] and rot0[] are indexed by SLOT, nullptr = not wanted)
 };
@@ -115,7 +116,7 @@ inline hipError_t device_setup(DeviceSetup &d, int device, const void *kern, int
 bool direct_supported(int T, int D);
 hipError_t launch_fir(const LaunchArgs &a, int variant);
 // overlap-save FFT backend (if_fir_fft.hip)
-constexpr int FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024 + 64); // ... + 64 NCO row phasors
+constexpr int FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024 + 64 + 256); // ... + 64 NCO row phasors + 256 W2048 twiddles
 bool fft_supported(int T, int D);
 bool fft_two_partitions(int T); // 3074..4096 taps: two launches (2048 + the rest), see launch_fft
 struct FftSchedule

@@ -583,6 +583,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.diag = (fft_var && ctx->variant >= 1000 && ctx->variant < 2000) ? ctx->variant - 1000
              : (fft_var && ctx->variant >= 1000000 && ctx->variant < 3000000) ? ctx->variant - 1000000 : 0;
     a.grid_limit = (fft_var && ctx->variant > 2000 && ctx->variant < 3000) ? ctx->variant - 2000 : 0;
+    a.no_fold = ctx->variant == 3000;
 #endif
     if_fir::ChanArgs own_chan{};
     if (!chan && ctx->backend == IF_FIR_BACKEND_HIP_FFT && bank_route(ctx) && m > 0)

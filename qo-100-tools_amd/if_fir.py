@@ -374,7 +374,7 @@ class IfFir:
         return host
 
 
-FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024 + 64)
+FFT_TABLE_FLOATS = 2 * (4096 + 4096 + 256 + 1024 + 1024 + 64 + 256)
 
 
 def debug_fft_tables(taps, decimation, complex_taps=False, nco_delta=0):
@@ -388,7 +388,7 @@ def debug_fft_tables(taps, decimation, complex_taps=False, nco_delta=0):
         raise IfFirError("if_fir_debug_fft_tables: (taps=%d, decimation=%d) is not served by the overlap-save kernel" % (t, decimation))
     c = out.view(np.complex64)
     return {"tw1": c[0:4096], "hp": c[4096:8192], "tw2": c[8192:8448], "twd": c[8448:9472], "twe": c[9472:10496],
-            "ncob": c[10496:10560]}
+            "ncob": c[10496:10560], "twf": c[10560:10816]}
 
 
 def debug_fft_schedule(nblocks, workgroups=256):

@@ -148,6 +148,8 @@ def test_overlap_save_tables_against_numpy(fir, t, d, ctaps):
     r = np.arange(64, dtype=np.uint64)
     ph = ((r * np.uint64(64) * np.uint64(nco_delta)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 2.0 ** 32
     assert np.allclose(tab["ncob"], np.exp(2j * np.pi * ph), atol=1e-7)
+    for i in range(4):   # decimate-by-2 inverse (round 3): W2048^(16 k1 + k0), k0 = 4 (lane // 16) + i, k1 = lane % 16
+        assert np.allclose(tab["twf"][i * 64:i * 64 + 64], W(2048, 16 * (lane % 16) + 4 * (lane // 16) + i), atol=1e-7)
     # H in lane order
     H = np.fft.fft(h, 4096) / 4096.0
     Hp = np.zeros((4, 16, 64), dtype=np.complex128)
@@ -260,8 +262,9 @@ def test_no_overlap_save_instantiation_spills():
         elif cur:
             kernels[cur][k.split("[")[0].strip()] = int(v)
     fft = {k: v for k, v in kernels.items() if "fir_fft_kernel" in k}
-    # 5 overlap lengths x (4 + 4 + 4 single-channel, 2 + 4 + 4 filter-bank: decimation 4, and 8 / 16 with and without NCO) variants + 8 accumulating ones
-    assert len(fft) == 118, len(fft)
+    # 5 overlap lengths x (4 + 4 + 4 + 4 single-channel: full rate, decimate-by-4, -by-2, selecting store; 2 + 4 + 4 filter-bank: decimation 4,
+    # and 8 / 16 with and without NCO) variants + 8 accumulating ones
+    assert len(fft) == 138, len(fft)
     for name, res in fft.items():
         assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
 

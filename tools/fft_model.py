@@ -359,3 +359,60 @@ def main_bank8():
 
 if __name__ == "__main__":
     main_bank8()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# decimate-by-2 variant (round 3): fold the 2 aliases (k2 = k2' + 8 j, k2' in 0..7) and run a 2048-point inverse
+#   k' = k0 + 16*k1 + 256*k2'                              m' = mu2 + 8*mu1 + 128*mu0    (mu2 in 0..7)
+#   A: 8-point iDFT over k2' -> slot (i, mu2); twiddle conj W2048^((16*k1 + k0)*mu2)
+#   two calls of the common tail, hb = mu2 >> 2, low = mu2 & 3:  lane = 4 mu1 + low, slot mu0: y_D[128 mu0 + 8 mu1 + 4 hb + low]
+def inverse_dec2(p3):
+    lane = np.arange(64)
+    g, m = lane // 16, lane % 16
+    out = np.zeros(2048, dtype=np.complex128)
+    a8 = np.zeros((32, 64), dtype=np.complex128)         # slot (i, mu2) := 8 i + mu2
+    for i in range(4):
+        z = np.stack([p3[16 * i + k2p] + p3[16 * i + k2p + 8] for k2p in range(8)])
+        seq = np.fft.ifft(z, axis=0) * 8
+        for mu2 in range(8):
+            a8[8 * i + mu2] = seq[mu2] * np.conj(W(2048, (16 * m + 4 * g + i) * mu2))
+    for hb in range(2):
+        a = np.zeros((16, 64), dtype=np.complex128)       # slot 4 i + low
+        for i in range(4):
+            for low in range(4):
+                a[4 * i + low] = a8[8 * i + 4 * hb + low]
+        xx = np.zeros_like(a)
+        for gg in range(4):
+            xx[:, 16 * gg:16 * gg + 16] = a[:, 16 * gg:16 * gg + 16].T
+        j = lane % 16
+        i_l, low_l = j // 4, j % 4
+        k0_l = 4 * g + i_l
+        bb = np.fft.ifft(xx, axis=0) * 16
+        for mu1 in range(16):
+            bb[mu1] = bb[mu1] * np.conj(W(256, k0_l * mu1))
+        y = np.zeros_like(bb)
+        for src in range(64):
+            for mu1 in range(16):
+                y[k0_l[src], 4 * mu1 + low_l[src]] = bb[mu1, src]
+        c = np.fft.ifft(y, axis=0) * 16
+        for mu0 in range(16):
+            for ln in range(64):
+                out[128 * mu0 + 8 * (ln >> 2) + 4 * hb + (ln & 3)] = c[mu0, ln]
+    return out / N
+
+
+def main_dec2():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    h = rng.standard_normal(255)
+    H = np.fft.fft(h, N)
+    Hp = np.zeros((64, 64), dtype=np.complex128)
+    for slot in range(64):
+        Hp[slot] = H[k_of(slot, np.arange(64))]
+    yd = inverse_dec2(forward(x) * Hp)
+    full = np.convolve(x, h)[:N]
+    print("dec2 valid-part err", np.max(np.abs(yd[128:] - full[256::2])))
+
+
+if __name__ == "__main__":
+    main_dec2()
