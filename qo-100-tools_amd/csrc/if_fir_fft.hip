@@ -364,25 +364,6 @@ struct DevQueue
     __device__ __forceinline__ unsigned wgs() const { return gridDim.x; }
 };
 
-// 8-point inverse DFT (unnormalised), natural order in and out: two 4-point butterflies + W8 twiddles
-__device__ __forceinline__ void ifft8(cf (&v)[8])
-{
-    constexpr float R = 0.70710678118654752f;
-    cf e[4], o[4];
-    bfly4<true>(v[0], v[2], v[4], v[6], e[0], e[1], e[2], e[3]);
-    bfly4<true>(v[1], v[3], v[5], v[7], o[0], o[1], o[2], o[3]);
-    o[1] = cmul_s<false>(o[1], (cf){R, R});   // exp(+j pi / 4)
-    o[3] = cmul_s<false>(o[3], (cf){-R, R});  // exp(+j 3 pi / 4)
-    v[0] = e[0] + o[0];
-    v[4] = e[0] - o[0];
-    v[1] = e[1] + o[1];
-    v[5] = e[1] - o[1];
-    v[2] = add_rot<true>(e[2], o[2]);         // e + j o
-    v[6] = sub_rot<true>(e[2], o[2]);
-    v[3] = e[3] + o[3];
-    v[7] = e[3] - o[3];
-}
-
 // common tail of the small inverses: a[j], j = 4 i + low (low = mu2 of the 1024-point inverse, or the channel-in-batch of the
 // 16-slot bank), k0 = 4 g + i, k1 = lane % 16:
 //   X: row transposition (one round of exchange 2): element j of lane (g, k1) -> lane (g, j), slot k1; iFFT16 over k1 -> mu1
@@ -796,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         }
         else if constexpr (CHAN == 2)
         {
-            // ---- decimate-by-2 tail (round 3; tools/fft_model.py inverse_dec2): pass 3, multiply by H/4096, fold the 2 aliases
+            // ---- decimate-by-2 tail (round 3): pass 3, multiply by H/4096, fold the 2 aliases
             // (k2 = k2' + 8 j) in place: r[phys(i, k2')] = z(i, k2'), k2' = 0..7; the other 8 registers of the group are dead
             // and refilled with rows of the next block right away
 #pragma unroll
@@ -820,74 +801,88 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
                 }
             }
-            // 2048-point inverse (8 x 16 x 16): 8-point inverse over k2' -> mu2, twiddle conj W2048^((16 k1 + k0) mu2) =
-            // conj(W2048^x)^(mu2 & 1) * conj(W1024^(x (mu2 >> 1))), then the common tail twice (hb = mu2 >> 2, low = mu2 & 3):
-            // lane = 4 mu1 + low, slot mu0 -> y_D[128 mu0 + 8 mu1 + 4 hb + low]
+            // 2048-point inverse as TWO 1024-point inverses (even and odd outputs), so that every lane ends up with two
+            // ADJACENT outputs and a store instruction writes 1 KiB contiguously (the first form of this tail, an 8-point
+            // stage + the common tail twice, left each instruction with 32-byte pieces 64 bytes apart: 1.14 ms against 0.73 ms
+            // of the selecting store, profiles/r03_decimate_2_tail.txt):
+            //   y[2p]   = IFFT1024( Z[k] + Z[k + 1024] ),   y[2p+1] = IFFT1024( (Z[k] - Z[k + 1024]) conj W2048^k ),
+            //   k = k0 + 16 k1 + 256 q, q = 0..3 (k + 1024 is k2' + 4);  W2048^k = W2048^(16 k1 + k0) W8^q
+            // in place: r[phys(i, q)] = even spectrum, r[phys(i, q + 4)] = odd spectrum
+            constexpr float R8 = 0.70710678118654752f;
 #pragma unroll
             for (int i = 0; i < 4; i++)
             {
-                cf z[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    z[j] = r[phys(i, j)];
-                ifft8(z);
                 const f2v wf = twf[i * 64 + lane];
 #pragma unroll
-                for (int mu2 = 1; mu2 < 8; mu2++)
+                for (int q = 0; q < 4; q++)
                 {
-                    if (mu2 & 1)
-                        z[mu2] = cmul_v<true>(z[mu2], wf);
-                    if (mu2 >> 1)
-                        z[mu2] = cmul_v<true>(z[mu2], twd[(i * 4 + (mu2 >> 1)) * 64 + lane]);
+                    const cf u = r[phys(i, q)], v = r[phys(i, q + 4)];
+                    r[phys(i, q)] = u + v;
+                    cf d = cmul_v<true>(u - v, wf);
+                    if (q == 1)
+                        d = cmul_s<false>(d, (cf){R8, R8});
+                    else if (q == 2)
+                        d = (cf){-d.y, d.x}; // * (+j)
+                    else if (q == 3)
+                        d = cmul_s<false>(d, (cf){-R8, R8});
+                    r[phys(i, q + 4)] = d;
                 }
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    r[phys(i, j)] = z[j];
             }
-            constexpr int MU0_FIRST = OVL_ROWS / 4; // 128 decimated outputs per mu0 slot = 256 input samples = 4 rows
-            cf a_lane = {1.0f, 0.0f}, hb_step = {1.0f, 0.0f};
+            constexpr int MU0_FIRST = OVL_ROWS / 4; // 64 output PAIRS per mu0 slot = 256 input samples = 4 rows
+            // NCO: outputs m = obase + 128 (mu0 - first) + 2 lane (+ 1) are rotated by phasor(phi0 + delta m): a lane factor
+            // (formed here, ahead of the inverses, while registers are free), a wave-uniform step for the odd output, and the
+            // row table (entries 64 full-rate rows = 32 outputs apart: entry 4 k)
+            cf a_lane = {1.0f, 0.0f}, a_odd = {1.0f, 0.0f};
             if constexpr (NCO)
             {
-                // output m = obase + 128 (mu0 - first) + 8 mu1 + 4 hb + low is rotated by phasor(phi0 + delta m): a lane
-                // factor, a wave-uniform factor for hb = 1 and the row table (its entries are 64 full-rate rows apart = 32
-                // decimated outputs: slot k of this tail is entry 4 k)
-                const float2 pa = nco_phasor(nco_phi0 + nco_delta * ((uint32_t)obase + 8u * (uint32_t)(lane >> 2) + (uint32_t)(lane & 3)));
+                const float2 pa = nco_phasor(nco_phi0 + nco_delta * ((uint32_t)obase + 2u * (uint32_t)lane));
                 a_lane = (cf){pa.x, pa.y};
-                const float2 ph = nco_phasor(4u * nco_delta);
-                hb_step = (cf){__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ph.x))),
-                               __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ph.y)))};
+                const float2 ph = nco_phasor(nco_delta);
+                const cf odd = {__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ph.x))),
+                                __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ph.y)))};
+                a_odd = cmul_s<false>(a_lane, odd);
             }
-            (void)a_lane; (void)hb_step;
-#pragma unroll
-            for (int hb = 0; hb < 2; hb++)
+            (void)a_lane; (void)a_odd;
+            cf ce[16], co[16];
             {
-                cf a[16];
+                cf z[16];
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int q = 0; q < 4; q++)
-                        a[4 * i + q] = r[phys(i, 4 * hb + q)];
-                if (hb == 1 && next_fast) // the last 32 registers are free now: the rest of the next block's rows
-                {
+                        z[4 * i + q] = r[phys(i, q)];
+                inverse_dec4(z, ce, twd, twe, xb, lane);
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
+                for (int i = 0; i < 4; i++)
 #pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
-                }
-                cf c[16];
-                inverse_tail256(a, c, twe, xb, lane);
-                if constexpr (NCO)
-                {
-                    const cf al = hb ? cmul_s<false>(a_lane, hb_step) : a_lane;
-#pragma unroll
-                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                        c[mu0] = cmul_v<false>(c[mu0], cmul_v<false>(al, ncob[4 * (mu0 - MU0_FIRST)]));
-                }
-                const unsigned vo = (8u * (unsigned)(lane >> 2) + 4u * hb + (unsigned)(lane & 3)) * 8u;
+                    for (int q = 0; q < 4; q++)
+                        z[4 * i + q] = r[phys(i, q + 4)];
+                inverse_dec4(z, co, twd, twe, xb, lane);
+            }
+            if constexpr (NCO)
+            {
 #pragma unroll
                 for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                    buf_store(osrd, vo, (mu0 - MU0_FIRST) * 1024, c[mu0]);
+                {
+                    ce[mu0] = cmul_v<false>(ce[mu0], cmul_v<false>(a_lane, ncob[4 * (mu0 - MU0_FIRST)]));
+                    co[mu0] = cmul_v<false>(co[mu0], cmul_v<false>(a_odd, ncob[4 * (mu0 - MU0_FIRST)]));
+                }
+            }
+            if (next_fast) // the other half of the next block's rows
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+            }
+#pragma unroll
+            for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+            {
+                typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+                const u32x4s_t w = {__float_as_uint(ce[mu0].x), __float_as_uint(ce[mu0].y), __float_as_uint(co[mu0].x),
+                                    __float_as_uint(co[mu0].y)};
+                __builtin_amdgcn_raw_buffer_store_b128(w, osrd, (unsigned)lane * 16u, (mu0 - MU0_FIRST) * 1024, IF_FIR_FFT_STORE_AUX);
             }
         }
         else if constexpr (CHAN == 8)

@@ -401,6 +401,27 @@ def inverse_dec2(p3):
     return out / N
 
 
+def inverse_dec2_even_odd(p3):
+    """the form the kernel uses: y[2p] = IFFT1024(Z[k] + Z[k+1024]), y[2p+1] = IFFT1024((Z[k] - Z[k+1024]) conj W2048^k), both
+    through inverse_dec4's machinery (here: its input convention is slot (i, k2') with the 4 aliases ALREADY to be folded, so
+    the even / odd spectra are placed at k2' = 0..3 and the other 12 alias slots are zero)"""
+    lane = np.arange(64)
+    g, m = lane // 16, lane % 16
+    out = np.zeros(2048, dtype=np.complex128)
+    ze = np.zeros_like(p3)
+    zo = np.zeros_like(p3)
+    for i in range(4):
+        for q in range(4):
+            u = p3[16 * i + q] + p3[16 * i + q + 8]          # fold the 2 aliases: Z(k2' = q)
+            v = p3[16 * i + q + 4] + p3[16 * i + q + 12]     # Z(k2' = q + 4)
+            k = (4 * g + i) + 16 * m + 256 * q
+            ze[16 * i + q] = u + v
+            zo[16 * i + q] = (u - v) * np.conj(W(2048, k))
+    out[0::2] = inverse_dec4(ze)
+    out[1::2] = inverse_dec4(zo)
+    return out
+
+
 def main_dec2():
     rng = np.random.default_rng(5)
     x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
@@ -412,6 +433,8 @@ def main_dec2():
     yd = inverse_dec2(forward(x) * Hp)
     full = np.convolve(x, h)[:N]
     print("dec2 valid-part err", np.max(np.abs(yd[128:] - full[256::2])))
+    ye = inverse_dec2_even_odd(forward(x) * Hp)
+    print("dec2 (even/odd form) valid-part err", np.max(np.abs(ye[128:] - full[256::2])))
 
 
 if __name__ == "__main__":
