@@ -876,13 +876,20 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int j = 0; j < 8; j++)
                         load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
             }
+            unsigned vo128 = (unsigned)lane * 16u;
 #pragma unroll
             for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
             {
                 typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
                 const u32x4s_t w = {__float_as_uint(ce[mu0].x), __float_as_uint(ce[mu0].y), __float_as_uint(co[mu0].x),
                                     __float_as_uint(co[mu0].y)};
-                __builtin_amdgcn_raw_buffer_store_b128(w, osrd, (unsigned)lane * 16u, (mu0 - MU0_FIRST) * 1024, IF_FIR_FFT_STORE_AUX);
+                // The row offset goes into the VECTOR offset, the scalar offset stays the literal 0: with a 16-byte store whose
+                // row offset sat in an SGPR the compiler placed no wait state between the store and the next (inline-asm) VALU
+                // write of its data registers, and the second dword of the data arrived corrupted now and then (found by the
+                // chunked-equals-unchunked GPU test; tools/diag_dec2.py).  In this form it inserts the s_nop the hazard needs.
+                __builtin_amdgcn_raw_buffer_store_b128(w, osrd, vo128, 0, IF_FIR_FFT_STORE_AUX);
+                vo128 += 1024u;
+                asm volatile("" : "+v"(vo128)); // one running offset register, not 15 precomputed ones
             }
         }
         else if constexpr (CHAN == 8)
