@@ -806,7 +806,7 @@ def main():
         else:
             rec = committed_traffic(args.workload, names[f.get_backend()])
             if rec and rec.get("hbm_bytes_per_launch") is not None:
-                traffic = rec.get("hbm_bytes_per_launch")
+                traffic = rec.get("hbm_bytes_per_launch") * len(owned)   # a step launches one kernel per owned channel
                 traffic_src = ("NOT measured in this run: TCC counters of kernel %s from the committed rocprofv3 "
                                "passes profiles/%s_* (another box), file profiles/traffic.json"
                                % (rec.get("kernel"), rec.get("round")))
