@@ -873,14 +873,33 @@ hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, i
 // attenuator).  HBM-bound reduction: 16-byte loads, float64 accumulation per lane (2^28 float32 squares overflow
 // float32's 24 bits of exactness), wave reduction by DPP-free shuffles, one float64 atomic per workgroup.
 // --------------------------------------------------------------------------------------------------------------
+// Each workgroup reads whole 32 KiB chunks (8 independent 16-byte loads per thread in flight, non-temporal: the buffer is
+// read once), chunks handed out grid-stride; float64 accumulation per lane, wave shuffles, one float64 atomic per workgroup.
+// (Round 3: the one-load-per-iteration grid-stride loop of round 1 streamed at 5.5 TB/s; see tools/ubench_mem2.hip for why the
+// shape of the loop matters.)
+constexpr int POWER_UNROLL = 8;
 __global__ __launch_bounds__(256) void power_kernel(const float4 *__restrict__ iq2, uint64_t pairs, const f2 *__restrict__ tail,
                                                    uint32_t tail_count, double *__restrict__ acc)
 {
     double s = 0.0;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride)
+    const uint64_t chunk = 256ull * POWER_UNROLL, nchunks = pairs / chunk;
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x)
     {
-        const float4 v = iq2[i]; // two samples
+        typedef float f4n __attribute__((ext_vector_type(4)));
+        const f4n *p = reinterpret_cast<const f4n *>(iq2 + c * chunk + threadIdx.x);
+        f4n v[POWER_UNROLL];
+#pragma unroll
+        for (int k = 0; k < POWER_UNROLL; k++)
+            v[k] = __builtin_nontemporal_load(p + k * 256);
+#pragma unroll
+        for (int k = 0; k < POWER_UNROLL; k++)
+            s += (double)v[k].x * (double)v[k].x + (double)v[k].y * (double)v[k].y + (double)v[k].z * (double)v[k].z +
+                 (double)v[k].w * (double)v[k].w;
+    }
+    // the pairs behind the last whole chunk, and the odd last sample
+    for (uint64_t i = nchunks * chunk + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (uint64_t)gridDim.x * 256)
+    {
+        const float4 v = iq2[i];
         s += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
     }
     if (blockIdx.x == 0 && threadIdx.x < tail_count)
@@ -904,9 +923,9 @@ hipError_t launch_power(const void *iq, uint64_t samples, double *acc, hipStream
     if (e != hipSuccess || samples == 0)
         return e;
     const uint64_t pairs = samples / 2;
-    uint64_t blocks = (pairs + 255) / 256;
-    if (blocks > 4096)
-        blocks = 4096;
+    uint64_t blocks = (pairs + 256 * POWER_UNROLL - 1) / (256 * POWER_UNROLL);
+    if (blocks > 2048)
+        blocks = 2048; // 8 workgroups per CU: enough loads in flight, few atomics
     if (blocks == 0)
         blocks = 1;
     hipLaunchKernelGGL(power_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(iq), pairs,

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, __graft_entry__ as g
 fir=g.load_pkg().if_fir
 torch.cuda.set_device(0)
