@@ -876,7 +876,8 @@ def test_random_configurations_against_the_oracle(fir, oracle):
         if b in (fir.BACKEND_HIP_DIRECT, fir.BACKEND_HIP_GENERIC) and not nco:
             assert np.array_equal(y, oracle.fir_f32fma(taps, x, d, **SEG)), (case, t, d, n, names[b])
         done[names[b]] += 1
-    assert all(v >= 3 for v in done.values()), done
+    if "IF_FIR_TEST_SEED" not in os.environ:   # (soak seeds draw the backends as they come; the default seed covers all four)
+        assert all(v >= 3 for v in done.values()), done
 
 
 def test_contexts_on_concurrent_threads(fir, oracle):
