@@ -165,7 +165,8 @@ constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_TWD = 65536 + 20
 static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 constexpr int LDS_Q = LDS_XB + FFT_WAVES * XBUF; // workgroup block queue: slot counter (16 B) + ring of group entries
 constexpr int LDS_QPTR = LDS_Q + 16 + Q_RING * 8; // 16-slot bank: the 16 output pointers (kept out of the SGPRs)
-constexpr int FFT_LDS_BYTES = LDS_QPTR + 16 * 8;
+constexpr int LDS_QNCO = LDS_QPTR + 16 * 8; // bank tails with an NCO: the block's rotation phasor, one 8-byte word per wave
+constexpr int FFT_LDS_BYTES = LDS_QNCO + FFT_WAVES * 8;
 
 __device__ __forceinline__ void exchange1_fwd(cf (&r)[64])
 {
@@ -678,15 +679,14 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         // outputs beyond M are dropped by the descriptor's bounds check
         const int64_t obase = blk * LOUT;
         const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
-        // filter-bank tails with an NCO: the block's share of the output rotation, phasor(phi0 + delta obase), wave-uniform
-        cf nco_blk = {1.0f, 0.0f};
-        if constexpr (NCO && CHAN != 0)
+        // filter-bank tails with an NCO: the block's share of the output rotation, phasor(phi0 + delta obase), wave-uniform;
+        // parked in a per-wave LDS word until the tails need it (the 16-slot tail has neither SGPRs nor VGPRs to spare)
+        if constexpr (NCO && (CHAN == 8 || CHAN == 16))
         {
             const float2 pb = nco_phasor(nco_phi0 + nco_delta * (uint32_t)obase);
-            nco_blk = (cf){__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pb.x))),
-                           __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pb.y)))};
+            if (lane == 0)
+                *reinterpret_cast<cf *>(smem + LDS_QNCO + wid * 8) = (cf){pb.x, pb.y};
         }
-        (void)nco_blk;
         if constexpr (CHAN == 16)
         {
             // ---- 16-slot filter bank at the channel rate (decimation 16, round 3; tools/fft_model.py bank16) --------------
@@ -745,8 +745,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     float2 *po = reinterpret_cast<float2 *const *>(smem + LDS_QPTR)[4 * b + cs];
                     cf wl = ncob[16 + (((4 * b + cs) * (int)chan.rot_e) & 15)];
                     if constexpr (NCO)
-                        wl = cmul_v<false>(cmul_s<false>(wl, nco_blk), ncob[32 + mu1]);
-                    const int64_t o0 = obase + mu1;
+                        wl = cmul_v<false>(cmul_v<false>(wl, *reinterpret_cast<const cf *>(smem + LDS_QNCO + wid * 8)), ncob[32 + mu1]);
+                    // decimation 32 / 64 through this tail (single channel): M and the indices count fs/16-rate outputs; every
+                    // sub-th of them (sub = 2, 4; obase and the slot steps are multiples of 16) is a real output: the other
+                    // lanes get an index beyond M
+                    const int sh = (int)chan.sub >> 1; // sub 1, 2, 4 -> shift 0, 1, 2
+                    const int64_t o0 = (((unsigned)mu1 & (chan.sub - 1u)) == 0u) ? obase + mu1 : M;
                     if (po != nullptr && !(diag & 2))
                     {
 #pragma unroll
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                                     v = cmul_v<false>(c[mu0], cmul_v<false>(wl, ncob[mu0 - MU0_FIRST]));
                                 else
                                     v = cmul_v<false>(c[mu0], wl);
-                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + (idx >> sh));
                             }
                         }
                     }
@@ -969,7 +973,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 cf wl = ((sl & lane) & 1) ? (cf){-r0.x, -r0.y} : r0;
                 const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
                 if constexpr (NCO) // as in the 16-slot tail: phasor(phi0 + delta m) = [block, uniform] * [lane: entries 32..63] * B(mu0 - first)
-                    wl = cmul_v<false>(cmul_s<false>(wl, nco_blk), ncob[32 + 2 * (lane >> 2) + (lane & 1)]);
+                    wl = cmul_v<false>(cmul_v<false>(wl, *reinterpret_cast<const cf *>(smem + LDS_QNCO + wid * 8)),
+                                       ncob[32 + 2 * (lane >> 2) + (lane & 1)]);
                 if (cl < nch && !(diag & 2))
                 {
 #pragma unroll
@@ -1287,7 +1292,9 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     }
     // DECN: the kernel runs at full rate over the N inputs (blocks, run queue, history as for D = 1) and keeps every
     // D-th output, the first one at full-rate index n0
-    const int64_t m_rate = DECN ? a.N : a.M;
+    // (16-slot tail used for decimation 32 / 64: it runs at the fs/16 rate and keeps every sub-th output)
+    const int64_t chan_sub = (CHAN == 16 && a.chan && a.chan->sub > 1) ? (int64_t)a.chan->sub : 1;
+    const int64_t m_rate = DECN ? a.N : CHAN == 16 ? (a.M - 1) * chan_sub + 1 : a.M;
     const int32_t n0_rate = DECN ? 0 : a.n0;
     const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
     if (nblocks <= 0)
@@ -1317,7 +1324,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist_full), a.hist_len, a.N,
                        n0_rate, m_rate, nblocks, (unsigned int *)a.queue,
                        (unsigned long long *)a.dbg, (int32_t)a.diag,
-                       DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a), DECN ? 0u - a.nco_word : nco_delta(a),
+                       DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a),
+                       DECN ? 0u - a.nco_word : CHAN == 16 ? 0u - a.nco_word * 16u : nco_delta(a),
                        a.chan ? *a.chan : ChanArgs{}, qsel, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M,
                        (int32_t)a.in_shift);
     const hipError_t le = hipGetLastError();
@@ -1353,7 +1361,8 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
 {
     if (a.chan)
     {
-        if ((a.D != 4 && a.D != 8 && a.D != 16) || a.chan->count < 1 || a.chan->count > CHAN_MAX ||
+        const bool sub_ok = (a.D == 32 || a.D == 64) && a.chan->sub == (uint32_t)a.D / 16u; // decimation 32 / 64: the 16-slot tail
+        if ((a.D != 4 && a.D != 8 && a.D != 16 && !sub_ok) || a.chan->count < 1 || a.chan->count > CHAN_MAX ||
             (a.D == 4 && (a.nco_word || a.ctaps)))
             return hipErrorInvalidConfiguration;
         const int ckey = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
@@ -1365,7 +1374,7 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
             case 2: return launch_fft_t<ROWS, true, true, false, 8>(a);
             default: return launch_fft_t<ROWS, true, true, true, 8>(a);
             }
-        if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
+        if (a.D >= 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
             switch (ckey)
             {
             case 0: return launch_fft_t<ROWS, true, false, false, 16>(a);

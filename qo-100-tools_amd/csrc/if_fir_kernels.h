@@ -28,6 +28,7 @@ struct ChanArgs
     float2 *out[CHAN_MAX];   // device, M samples each
     uint32_t mask16;         // decimation 16: bit s set = slot s is wanted (out[s] non-null)
     uint32_t rot_e;          // decimation 16: (abs0 + n0) mod 16: slot s is rotated by W16^(s rot_e) at this call's first output
+    uint32_t sub;            // decimation 16 tail used for decimation 32 / 64 (single channel): keep every sub-th output (1, 2, 4)
 };
 
 struct LaunchArgs

@@ -83,13 +83,15 @@ static void set_err(const if_fir_ctx *ctx, const char *fmt, ...)
 static inline int eff_ctaps(const if_fir_ctx *ctx) { return ctx->ctaps || ctx->nco_word; }
 static inline const float *eff_taps(const if_fir_ctx *ctx) { return ctx->h_eff ? ctx->h_eff : ctx->h_taps; }
 
-// Decimation 8 and 16 run as a ONE-channel filter bank at slot 0 on the overlap-save backend (round 3): the alias fold happens
+// Decimation 8 and 16 (and 32 / 64: the decimate-by-16 tail keeping every 2nd / 4th output) run as a ONE-channel filter bank at
+// slot 0 on the overlap-save backend (round 3): the alias fold happens
 // in the frequency domain and a 512- / 256-point inverse replaces the full-rate inverse + selecting store (≈ 1.8 k instead of
 // 2.9 k VALU instructions per block).  Real or complex taps, with or without the NCO (the tuned-and-decimated channel of an
 // SDR); two-partition filters and every other decimation keep the selecting store.
 static inline bool bank_route(const if_fir_ctx *ctx)
 {
-    return (ctx->D == 8 || ctx->D == 16) && !if_fir::fft_two_partitions(ctx->T) && ctx->variant != 3000;
+    return (ctx->D == 8 || ctx->D == 16 || ctx->D == 32 || ctx->D == 64) && !if_fir::fft_two_partitions(ctx->T) &&
+           ctx->variant != 3000;
 }
 
 // AUTO: the fastest backend that meets SPEC §3.  Measured over (taps, decimation) from 3 taps to 4095 and decimation
@@ -202,8 +204,9 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
         return 0;
     }
     // (the NCO's effective complex taps and its per-output phase step, like the single-channel tables)
-    if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)ctx->D,
-                             ctx->in_i16 ? 0x1p-15 : 1.0, tab, ctx->D);
+    const int bank = ctx->D == 8 ? 8 : 16; // decimation 32 / 64 use the decimate-by-16 tail (its NCO steps are per fs/16 output)
+    if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)bank,
+                             ctx->in_i16 ? 0x1p-15 : 1.0, tab, bank);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables_bank, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
@@ -594,6 +597,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
         own_chan.count = 1;
         own_chan.slot[0] = 0;
         own_chan.out[0] = (float2 *)out;
+        own_chan.sub = ctx->D >= 16 ? (uint32_t)ctx->D / 16u : 1u;
         for (int k = 0; k < 7; k++)
             own_chan.tw[0][2 * k] = 1.0f;
         chan = &own_chan;
@@ -602,23 +606,25 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     {
         // mix-down phase of every channel at this call's first output: exp(-j 2 pi slot (consumed + n0) / 16)
         // (decimation 16: the arrays are indexed by slot, all 16 are filled)
-        const uint32_t entries = ctx->D == 16 ? 16u : chan->count;
+        const uint32_t entries = ctx->D >= 16 ? 16u : chan->count;
         for (uint32_t c = 0; c < entries; c++)
         {
-            const uint32_t slot = ctx->D == 16 ? c : chan->slot[c];
+            const uint32_t slot = ctx->D >= 16 ? c : chan->slot[c];
             const uint32_t e = (uint32_t)((slot * ((ctx->consumed + n0) & 15u)) & 15u);
             chan->rot0[c][0] = (float)cos(-2.0 * M_PI * (double)e / 16.0);
             chan->rot0[c][1] = (float)sin(-2.0 * M_PI * (double)e / 16.0);
         }
-        if (ctx->D == 16)
+        if (ctx->D >= 16)
         {
+            if (!chan->sub)
+                chan->sub = 1;
             chan->rot_e = (uint32_t)((ctx->consumed + n0) & 15u);
             chan->mask16 = 0;
             for (uint32_t c = 0; c < 16; c++)
                 chan->mask16 |= chan->out[c] ? (1u << c) : 0u;
         }
         a.chan = chan;
-        if (ctx->D == 16 || ctx->D == 8)
+        if (ctx->D >= 8)
             a.fft_tables = ctx->d_fft_tables_bank;
     }
     a.queue_base = &ctx->queue_base;
