@@ -107,6 +107,8 @@ uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant);
 /* (calls on a stream that is being captured into a hipGraph are refused: the streaming state advances on the host) */
 /* run on a caller-owned HIP stream (pass a hipStream_t as void*; NULL = the context's own stream) */
 uint8_t if_fir_set_stream(if_fir_ctx_t *pCtx, void *pStream);
+/* waits for the context's stream; also fails (0 + message) if the overlap-save kernel's block queue reported an expired
+ * bounded wait since the last check -- outputs would then be incomplete; it never should */
 uint8_t if_fir_synchronize(if_fir_ctx_t *pCtx);
 /* last error message of this context (or of the failed if_fir_init when pCtx is NULL); never NULL */
 const char *if_fir_last_error(const if_fir_ctx_t *pCtx);

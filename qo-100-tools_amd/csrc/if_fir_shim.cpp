@@ -487,13 +487,30 @@ IF_FIR_API uint8_t if_fir_set_stream(if_fir_ctx_t *pCtx, void *pStream)
     return 1;
 }
 
+// The overlap-save kernel's block queue bounds every wait (if_fir_fft_queue.h): a wave that gives up leaves its blocks
+// unwritten and counts a fault in the queue block.  That must never happen; if it does, the caller is told here instead of
+// being handed incomplete outputs silently.
+static uint8_t check_queue_faults(if_fir_ctx *ctx)
+{
+    uint32_t faults = 0;
+    HIP_TRY(ctx, hipMemcpy(&faults, static_cast<const char *>(ctx->d_queue) + 8, 4, hipMemcpyDeviceToHost));
+    if (faults)
+    {
+        (void)hipMemset(static_cast<char *>(ctx->d_queue) + 8, 0, 4);
+        set_err(ctx, "overlap-save block queue: %u bounded wait(s) expired since the last check; outputs of the calls in between "
+                     "are incomplete (please report: this is a library defect)", faults);
+        return 0;
+    }
+    return 1;
+}
+
 IF_FIR_API uint8_t if_fir_synchronize(if_fir_ctx_t *pCtx)
 {
     if (!pCtx)
         return 0;
     HIP_TRY(pCtx, hipSetDevice(pCtx->device));
     HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
-    return 1;
+    return check_queue_faults(pCtx);
 }
 
 static inline uint64_t out_count(uint64_t consumed, uint64_t n, uint32_t d, uint32_t *pn0)
@@ -789,6 +806,8 @@ IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float
         if (m)
             HIP_TRY(pCtx, hipMemcpyAsync(pfIQOut, pCtx->d_stage_out, 8 * m, hipMemcpyDeviceToHost, pCtx->stream));
         HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+        if (!check_queue_faults(pCtx))
+            return 0;
         if (pullOutSamples)
             *pullOutSamples = m;
         return 1;
@@ -838,6 +857,8 @@ IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float
     }
     HIP_TRY(pCtx, hipStreamSynchronize(pCtx->copy_out));
     HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+    if (!check_queue_faults(pCtx))
+        return 0;
     if (pullOutSamples)
         *pullOutSamples = done_out;
     return 1;
