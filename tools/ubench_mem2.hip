@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <vector>
 #include <algorithm>
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -329,6 +330,40 @@ int main(int argc, char **argv)
         run_blocks<32, 8, 8, 0, 0, 512, 2>("4k persist", 256, 0, 1);
         run_blocks<32, 16, 16, 2, 2, 512, 2>("4k persist ntLS", 256, 0, 1);
         run_blocks<16, 16, 16, 2, 2, 512, 4>("2k 1shot ntLS", (int)((NSAMP * 8 / (16 * 1024 - 2048)) / 8), 5, 1);
+    }
+    if (!all && strstr(sel, "soak"))
+    {
+        // soak <seconds> [mix]: one pattern back to back for a while (power sampling from outside, tools/power_attr.sh):
+        // the filter's persistent skeleton (16-byte rows, nt loads and stores, 256 workgroups) or the one-shot 4:1 mix
+        const double secs = argc > 2 ? atof(argv[2]) : 8.0;
+        const bool mix = argc > 3 && strstr(argv[3], "mix");
+        constexpr long UB = 32 * 1024 - 2048;
+        MapArgs m;
+        m.nunits = (long)(NSAMP * 8 / UB);
+        m.waves = 256 * 8; m.map = 0; m.run = 1; m.wgs = 256; m.queue = g_queue;
+        const long nout = (long)(inb / 16) / 4;
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        const auto t0 = std::chrono::steady_clock::now();
+        float ms = 0;
+        long launches = 0;
+        do
+        {
+            CHECK(hipEventRecord(e0));
+            for (int i = 0; i < 200; i++)
+            {
+                if (mix)
+                    hipLaunchKernelGGL(mix41_oneshot<1>, dim3(nout / 256), dim3(256), 0, 0, (const f4 *)g_in, (f4 *)g_out, nout);
+                else
+                    hipLaunchKernelGGL((k_blocks<32, 16, 16, 2, 2, 512, 2, 0>), dim3(256), dim3(512), 0, 0, g_in, g_out, m);
+            }
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            launches += 200;
+        } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs);
+        printf("soak %s: %.4f ms per launch (last 200 of %ld), %.2f TB/s algorithmic\n", mix ? "mix 4:1 one-shot nt" : "persistent skeleton ntLS", ms / 200,
+               launches, 1.25 * inb / (ms / 200) / 1e9);
+        return 0;
     }
     if (want("shape"))
     {
