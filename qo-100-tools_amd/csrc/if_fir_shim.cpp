@@ -186,6 +186,10 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
     free(tab);
     if (e != hipSuccess)
     {
+        // never leave an allocated but unfilled image behind: the next call would take it for the tables
+        if (ctx->d_fft_tables)
+            (void)hipFree(ctx->d_fft_tables);
+        ctx->d_fft_tables = nullptr;
         set_err(ctx, "overlap-save tables: upload failed: %s", hipGetErrorString(e));
         return 0;
     }
@@ -492,11 +496,14 @@ IF_FIR_API uint8_t if_fir_set_stream(if_fir_ctx_t *pCtx, void *pStream)
 // being handed incomplete outputs silently.
 static uint8_t check_queue_faults(if_fir_ctx *ctx)
 {
+    // on the context's stream (callers have just synchronized it): a copy on the null stream would also wait for every
+    // blocking stream of the process
     uint32_t faults = 0;
-    HIP_TRY(ctx, hipMemcpy(&faults, static_cast<const char *>(ctx->d_queue) + 8, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpyAsync(&faults, static_cast<const char *>(ctx->d_queue) + 8, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (faults)
     {
-        (void)hipMemset(static_cast<char *>(ctx->d_queue) + 8, 0, 4);
+        (void)hipMemsetAsync(static_cast<char *>(ctx->d_queue) + 8, 0, 4, ctx->stream);
         set_err(ctx, "overlap-save block queue: %u bounded wait(s) expired since the last check; outputs of the calls in between "
                      "are incomplete (please report: this is a library defect)", faults);
         return 0;
@@ -572,6 +579,10 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
                      "streaming state and cannot be replayed");
         return 0;
     }
+    // (built at init / set_backend / set_nco; a failed rebuild after if_fir_set_nco or if_fir_set_input_format is retried here
+    // instead of launching without tables)
+    if (ctx->backend == IF_FIR_BACKEND_HIP_FFT && !ensure_fft_tables(ctx))
+        return 0;
     if_fir::LaunchArgs a{};
     a.in = in;
     a.out = out;
@@ -836,6 +847,7 @@ IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float
     // the copy streams must not run ahead of work already queued on the context's stream (earlier calls)
     HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
     uint64_t done_in = 0, done_out = 0;
+    const auto pipeline = [&]() -> uint8_t {
     for (uint32_t c = 0; c < nchunks; c++)
     {
         const uint64_t len = (ullSamples - done_in) < chunk ? (ullSamples - done_in) : chunk;
@@ -854,6 +866,17 @@ IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float
             HIP_TRY(pCtx, hipMemcpyAsync(pfIQOut + 2 * done_out, d_out, 8 * m, hipMemcpyDeviceToHost, pCtx->copy_out));
         done_in += len;
         done_out += m;
+    }
+    return 1;
+    };
+    if (!pipeline())
+    {
+        // a chunk failed: nothing of this call may still be reading or writing the caller's buffers when it returns
+        // (the error text of the failing step stays in place)
+        (void)hipStreamSynchronize(pCtx->copy_in);
+        (void)hipStreamSynchronize(pCtx->stream);
+        (void)hipStreamSynchronize(pCtx->copy_out);
+        return 0;
     }
     HIP_TRY(pCtx, hipStreamSynchronize(pCtx->copy_out));
     HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
@@ -1202,16 +1225,7 @@ IF_FIR_API uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat
     }
     const int old = pCtx->in_i16;
     pCtx->in_i16 = (ulFormat == IF_FIR_INPUT_I16);
-    if (old != pCtx->in_i16 && (pCtx->d_fft_tables || pCtx->d_fft_tables_bank)) // the tables carry the sample format's scale
-    {
-        HIP_TRY(pCtx, hipSetDevice(pCtx->device));
-        HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
-        if (pCtx->d_fft_tables)
-            (void)hipFree(pCtx->d_fft_tables);
-        if (pCtx->d_fft_tables_bank)
-            (void)hipFree(pCtx->d_fft_tables_bank);
-        pCtx->d_fft_tables = pCtx->d_fft_tables_bank = nullptr;
-    }
+    // would the requested backend still apply?  (decided before anything is changed)
     const uint32_t b = resolve_backend(pCtx, pCtx->backend_req);
     if (!backend_ok(pCtx, b))
     {
@@ -1219,13 +1233,29 @@ IF_FIR_API uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat
         set_err(pCtx, "if_fir_set_input_format: backend %u does not take this input format", pCtx->backend_req);
         return 0;
     }
-    if (b == IF_FIR_BACKEND_HIP_FFT && !ensure_fft_tables(pCtx))
+    if (old != pCtx->in_i16 && (pCtx->d_fft_tables || pCtx->d_fft_tables_bank)) // the tables carry the sample format's scale
     {
-        pCtx->in_i16 = old;
-        return 0;
+        hipError_t e = hipSetDevice(pCtx->device);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(pCtx->stream); // kernels in flight still read them
+        if (e != hipSuccess)
+        {
+            pCtx->in_i16 = old;
+            set_err(pCtx, "if_fir_set_input_format: %s", hipGetErrorString(e));
+            return 0;
+        }
+        if (pCtx->d_fft_tables)
+            (void)hipFree(pCtx->d_fft_tables);
+        if (pCtx->d_fft_tables_bank)
+            (void)hipFree(pCtx->d_fft_tables_bank);
+        pCtx->d_fft_tables = pCtx->d_fft_tables_bank = nullptr;
     }
     pCtx->backend = b;
-    if (old != pCtx->in_i16)
-        return if_fir_reset(pCtx); // the history buffer holds samples in the input format: start a fresh stream
+    // the history buffer holds samples in the input format: a changed format starts a fresh stream
+    if (old != pCtx->in_i16 && !if_fir_reset(pCtx))
+        return 0;
+    // (a failed upload leaves the tables unbuilt; every launch makes sure of them again, run_device)
+    if (b == IF_FIR_BACKEND_HIP_FFT && !ensure_fft_tables(pCtx))
+        return 0;
     return 1;
 }
