@@ -309,6 +309,50 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
     __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, IF_FIR_FFT_STORE_AUX);
 }
 
+// Decimations D = 4 * sub (8, 12, ..., 64) behind the decimate-by-4 tail: the tail
+// runs at the fs/F rate and every sub-th of its outputs is a real output.  The block grid starts at a kept output (the launcher
+// shifts it by the call's decimation phase), so tail output number i (counted over the whole call) is kept when i is a
+// multiple of sub, as output i / sub.  The block's share (obase) is divided once per block, wave-uniform, in SGPRs; each
+// output then costs a multiply-shift (ceil(2^18 / sub), exact for numerators below 2^12: remainder + lane offset + step
+// < 1100).  sub = 1 keeps everything.
+struct KeepEvery
+{
+    int64_t qU;     // floor(obase / sub), wave-uniform
+    unsigned rem;   // obase mod sub, wave-uniform
+    unsigned magic; // ceil(2^18 / sub)
+    unsigned sub;
+    // obase = blk * lout (blk < 2^31, lout <= 960): divided in 32-bit pieces, blk = bq sub + br ->
+    // obase / sub = bq lout + (br lout) / sub -- a 64-bit division here costs a dozen temporaries the tails do not have
+    __device__ __forceinline__ void init(int64_t blk, unsigned lout, unsigned sub_)
+    {
+        sub = sub_ ? sub_ : 1u;
+        uint64_t q;
+        if ((sub & (sub - 1u)) == 0u) // 1, 2, 4: a shift
+        {
+            const uint64_t ob = (uint64_t)blk * lout;
+            rem = (unsigned)ob & (sub - 1u);
+            q = ob >> __builtin_ctz(sub);
+        }
+        else
+        {
+            const unsigned bq = (unsigned)blk / sub, br = (unsigned)blk - bq * sub;
+            const unsigned t = br * lout, q2 = t / sub;
+            rem = t - q2 * sub;
+            q = (uint64_t)bq * lout + q2;
+        }
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+        qU = (int64_t)(((uint64_t)hi << 32) | lo);
+        rem = (unsigned)__builtin_amdgcn_readfirstlane(rem);
+        magic = (unsigned)__builtin_amdgcn_readfirstlane((262144u + sub - 1u) / sub);
+    }
+    // tail output `off` of this block (lane offset + step): its index among the call's kept outputs, or -1
+    __device__ __forceinline__ int64_t index(unsigned off) const
+    {
+        const unsigned u = rem + off, qd = (u * magic) >> 18;
+        return (u - qd * sub == 0u) ? qU + (int64_t)qd : (int64_t)-1;
+    }
+};
+
 // ---- block queue (two levels): if_fir_fft_queue.h, shared with the host simulation --------------------------------------
 // LDS image: the current-group word at LDS_Q, the look-ahead ring at LDS_Q + 16.
 struct DevQueue
@@ -433,7 +477,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
     // CHAN names the decimating tail beyond the plain decimate-by-4 one: 2 = single channel, decimation 2 (frequency-domain
     // fold + 2048-point inverse); 4 / 8 / 16 = the filter bank at that decimation
-    static_assert(CHAN == 0 || ((CHAN == 2 || CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4), "decimating tails: 2, or the bank at 4, 8, 16");
+    // (1 = the decimate-by-4 tail keeping every sub-th output: decimation 8, 12, ..., 64)
+    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4), "decimating tails: 1, 2, or the bank at 4, 8, 16");
     static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
@@ -746,11 +791,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     cf wl = ncob[16 + (((4 * b + cs) * (int)chan.rot_e) & 15)];
                     if constexpr (NCO)
                         wl = cmul_v<false>(cmul_v<false>(wl, *reinterpret_cast<const cf *>(smem + LDS_QNCO + wid * 8)), ncob[32 + mu1]);
-                    // decimation 32 / 64 through this tail (single channel): M and the indices count fs/16-rate outputs; every
-                    // sub-th of them (sub = 2, 4; obase and the slot steps are multiples of 16) is a real output: the other
-                    // lanes get an index beyond M
-                    const int sh = (int)chan.sub >> 1; // sub 1, 2, 4 -> shift 0, 1, 2
-                    const int64_t o0 = (((unsigned)mu1 & (chan.sub - 1u)) == 0u) ? obase + mu1 : M;
+                    const int64_t o0 = obase + mu1;
                     if (po != nullptr && !(diag & 2))
                     {
 #pragma unroll
@@ -764,7 +805,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                                     v = cmul_v<false>(c[mu0], cmul_v<false>(wl, ncob[mu0 - MU0_FIRST]));
                                 else
                                     v = cmul_v<false>(c[mu0], wl);
-                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + (idx >> sh));
+                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
                             }
                         }
                     }
@@ -1123,9 +1164,31 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
                     c[mu0] = cmul_v<false>(c[mu0], cmul_v<false>(a_lane, ncob[mu0 - MU0_FIRST]));
             }
+            if constexpr (CHAN == 1)
+            {
+                // decimation 8, 12, ..., 64: every sub-th output of the decimate-by-4 tail is a real output.  Descriptor over the
+                // kept outputs from this block's first one on (decn_m of them in the call); a lane that keeps nothing, or an
+                // index beyond the end, is dropped by the bounds check.
+                const unsigned sub = chan.sub;
+                const int64_t qb = (obase + (int64_t)sub - 1) / (int64_t)sub; // wave-uniform
+                const srd_t dsrd = make_srd(out + qb, (diag & 2) ? 0 : (decn_m - qb) * 8);
+                KeepEvery ke;
+                ke.init(blk, (unsigned)LOUT, sub);
+                const int lim = (int)((M - obase) < 65536 ? (M - obase) : 65536); // tail outputs of the call left from this block on
 #pragma unroll
-            for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                buf_store(osrd, voff, (mu0 - MU0_FIRST) * 512, c[mu0]);
+                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                {
+                    const int64_t kept = ke.index((unsigned)lane + 64u * (unsigned)(mu0 - MU0_FIRST));
+                    const unsigned so = (kept >= 0 && lane + 64 * (mu0 - MU0_FIRST) < lim) ? (unsigned)(kept - qb) * 8u : 0xffffffffu;
+                    buf_store(dsrd, so, 0, c[mu0]);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    buf_store(osrd, voff, (mu0 - MU0_FIRST) * 512, c[mu0]);
+            }
         }
         else
         {
@@ -1292,9 +1355,11 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     }
     // DECN: the kernel runs at full rate over the N inputs (blocks, run queue, history as for D = 1) and keeps every
     // D-th output, the first one at full-rate index n0
-    // (16-slot tail used for decimation 32 / 64: it runs at the fs/16 rate and keeps every sub-th output)
-    const int64_t chan_sub = (CHAN == 16 && a.chan && a.chan->sub > 1) ? (int64_t)a.chan->sub : 1;
-    const int64_t m_rate = DECN ? a.N : CHAN == 16 ? (a.M - 1) * chan_sub + 1 : a.M;
+    // (decimation 4 sub behind the decimate-by-4 tail, CHAN == 1: the tail runs at the fs/4 rate and keeps every sub-th output)
+    constexpr int F = CHAN == 16 ? 16 : CHAN == 8 ? 8 : CHAN == 2 ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
+    ChanArgs ca = a.chan ? *a.chan : ChanArgs{};
+    ca.sub = CHAN == 1 ? (uint32_t)(a.D / 4) : 1u;
+    const int64_t m_rate = DECN ? a.N : (a.M - 1) * (int64_t)ca.sub + 1;
     const int32_t n0_rate = DECN ? 0 : a.n0;
     const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
     if (nblocks <= 0)
@@ -1325,8 +1390,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
                        n0_rate, m_rate, nblocks, (unsigned int *)a.queue,
                        (unsigned long long *)a.dbg, (int32_t)a.diag,
                        DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a),
-                       DECN ? 0u - a.nco_word : CHAN == 16 ? 0u - a.nco_word * 16u : nco_delta(a),
-                       a.chan ? *a.chan : ChanArgs{}, qsel, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M,
+                       DECN ? 0u - a.nco_word : 0u - a.nco_word * (uint32_t)F,
+                       ca, qsel, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M,
                        (int32_t)a.in_shift);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess && a.queue_valid)
@@ -1340,6 +1405,23 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 bool fft_supported(int T, int D)
 {
     return D >= 1 && D <= 64 && T >= 1 && T <= 4096;
+}
+
+// Which decimations have a decimating tail (frequency-domain alias fold + small inverse): D = F * sub with F the tail's own
+// decimation.  F = 2: decimation 2.  F = 4: decimation 4 and every other multiple of 4 up to 64 -- the decimate-by-4 tail keeping
+// every sub-th output (round 3; measured faster than the one-channel filter-bank tails at 8 / 16 it replaced for single channels,
+// profiles/r03_composite_decimations.txt).  Everything else (odd D, 2 x odd, filters of more than 3073 taps) runs the full-rate
+// kernel with a selecting store.  One definition for the launcher, the shim's tables and the multi-channel front's chunk grid.
+bool fft_tail(int T, int D, int *pF, int *pSub)
+{
+    int F = 1;
+    if (D >= 1 && D <= 64 && T >= 1 && T <= 3073)
+        F = (D == 2) ? 2 : (D % 4 == 0) ? 4 : 1;
+    if (pF)
+        *pF = F;
+    if (pSub)
+        *pSub = D / F;
+    return F > 1;
 }
 
 // 3074..4096 taps: two partitions of at most FFT_PART taps each, y = h_a * x + h_b * (x delayed by FFT_PART)
@@ -1359,10 +1441,12 @@ int fft_overlap_rows(int T)
 template <int ROWS>
 static hipError_t launch_fft_rows(const LaunchArgs &a)
 {
+    int F = 1;
+    const bool tail = fft_tail(a.T, a.D, &F, nullptr);
     if (a.chan)
     {
-        const bool sub_ok = (a.D == 32 || a.D == 64) && a.chan->sub == (uint32_t)a.D / 16u; // decimation 32 / 64: the 16-slot tail
-        if ((a.D != 4 && a.D != 8 && a.D != 16 && !sub_ok) || a.chan->count < 1 || a.chan->count > CHAN_MAX ||
+        // the filter bank (decimation 4, 8, 16)
+        if ((a.D != 4 && a.D != 8 && a.D != 16) || a.chan->count < 1 || a.chan->count > CHAN_MAX ||
             (a.D == 4 && (a.nco_word || a.ctaps)))
             return hipErrorInvalidConfiguration;
         const int ckey = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
@@ -1374,7 +1458,7 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
             case 2: return launch_fft_t<ROWS, true, true, false, 8>(a);
             default: return launch_fft_t<ROWS, true, true, true, 8>(a);
             }
-        if (a.D >= 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
+        if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
             switch (ckey)
             {
             case 0: return launch_fft_t<ROWS, true, false, false, 16>(a);
@@ -1400,6 +1484,14 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
         case 1: return launch_fft_t<ROWS, true, false, true>(a);
         case 2: return launch_fft_t<ROWS, true, true, false>(a);
         default: return launch_fft_t<ROWS, true, true, true>(a);
+        }
+    if (tail && F == 4) // decimation 8, 12, ..., 64: the decimate-by-4 tail keeping every sub-th output (tables as for decimation 4)
+        switch (key)
+        {
+        case 0: return launch_fft_t<ROWS, true, false, false, 1>(a);
+        case 1: return launch_fft_t<ROWS, true, false, true, 1>(a);
+        case 2: return launch_fft_t<ROWS, true, true, false, 1>(a);
+        default: return launch_fft_t<ROWS, true, true, true, 1>(a);
         }
     if (a.D == 1)
         switch (key)

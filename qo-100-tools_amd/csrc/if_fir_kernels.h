@@ -28,7 +28,7 @@ struct ChanArgs
     float2 *out[CHAN_MAX];   // device, M samples each
     uint32_t mask16;         // decimation 16: bit s set = slot s is wanted (out[s] non-null)
     uint32_t rot_e;          // decimation 16: (abs0 + n0) mod 16: slot s is rotated by W16^(s rot_e) at this call's first output
-    uint32_t sub;            // decimation 16 tail used for decimation 32 / 64 (single channel): keep every sub-th output (1, 2, 4)
+    uint32_t sub;            // decimate-by-4 tail at decimation 4 * sub (single channel): keep every sub-th output (set by the launcher)
 };
 
 struct LaunchArgs
@@ -131,6 +131,8 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                       int bank = 0);
 
 int fft_overlap_rows(int T);
+// decimating tail of (T, D): D = F * sub, F = 2 or 4 the tail's own decimation (false, F = 1: full-rate kernel + selecting store)
+bool fft_tail(int T, int D, int *pF, int *pSub);
 // history buffers hold the last `hist_len` samples of the stream (>= T-1; hist_in/hist_out: whole buffers)
 hipError_t launch_history(const void *in, const void *hist_in, void *hist_out, int hist_len, int64_t N, int in_i16,
                           hipStream_t stream);

@@ -436,12 +436,16 @@ static uint64_t mc_gcd(uint64_t a, uint64_t b)
     return a;
 }
 
-// The decimating tails of the overlap-save kernel (decimation 2, 4, and 8 / 16 / 32 / 64 through the one-channel filter bank; <= 3073
-// taps) anchor their block grid at the call's first OUTPUT (n0 samples into the call when the stream position is
-// off-phase); every other kernel anchors it at the call's first sample.
+// The decimating tails of the overlap-save kernel (if_fir::fft_tail: decimation 2, 4, 8, 16 and the multiples of 4, 8, 16 that keep
+// every sub-th tail output; <= 3073 taps) anchor their block grid at the call's first OUTPUT (n0 samples into the call when the
+// stream position is off-phase); every other kernel anchors it at the call's first sample.
+namespace if_fir
+{
+bool fft_tail(int T, int D, int *pF, int *pSub); // if_fir_fft.hip
+}
 static bool mc_grid_follows_phase(uint32_t taps, uint32_t decim)
 {
-    return (decim == 2 || decim == 4 || decim == 8 || decim == 16 || decim == 32 || decim == 64) && taps <= 3073;
+    return if_fir::fft_tail((int)taps, (int)decim, nullptr, nullptr);
 }
 
 // Chunk table of a call.  The effective chunk is the least common multiple of the requested chunk (a multiple of

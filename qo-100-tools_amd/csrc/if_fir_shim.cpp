@@ -83,15 +83,14 @@ static void set_err(const if_fir_ctx *ctx, const char *fmt, ...)
 static inline int eff_ctaps(const if_fir_ctx *ctx) { return ctx->ctaps || ctx->nco_word; }
 static inline const float *eff_taps(const if_fir_ctx *ctx) { return ctx->h_eff ? ctx->h_eff : ctx->h_taps; }
 
-// Decimation 8 and 16 (and 32 / 64: the decimate-by-16 tail keeping every 2nd / 4th output) run as a ONE-channel filter bank at
-// slot 0 on the overlap-save backend (round 3): the alias fold happens
-// in the frequency domain and a 512- / 256-point inverse replaces the full-rate inverse + selecting store (≈ 1.8 k instead of
-// 2.9 k VALU instructions per block).  Real or complex taps, with or without the NCO (the tuned-and-decimated channel of an
-// SDR); two-partition filters and every other decimation keep the selecting store.
-static inline bool bank_route(const if_fir_ctx *ctx)
+// The decimating tail of this context's (taps, decimation): D = F * sub (if_fir::fft_tail; F = 1: none)
+static inline int tail_factor(const if_fir_ctx *ctx, int *psub = nullptr)
 {
-    return (ctx->D == 8 || ctx->D == 16 || ctx->D == 32 || ctx->D == 64) && !if_fir::fft_two_partitions(ctx->T) &&
-           ctx->variant != 3000;
+    int F = 1, sub = 1;
+    if_fir::fft_tail(ctx->T, ctx->D, &F, &sub);
+    if (psub)
+        *psub = sub;
+    return F;
 }
 
 // AUTO: the fastest backend that meets SPEC §3.  Measured over (taps, decimation) from 3 taps to 4095 and decimation
@@ -176,8 +175,13 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
                                  ctx->in_i16 ? 0x1p-15 : 1.0, tab + if_fir::FFT_TABLE_FLOATS);
     }
     else
-        if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (ctx->D == 4 ? 4u : 1u),
+    {
+        // decimation 4 and its multiples (8, 12, ..., 64: the same tail keeping every sub-th output) take the merged table and
+        // NCO row steps of decimation 4; decimation 2 and the selecting-store route the plain one
+        const int F = tail_factor(ctx);
+        if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), F == 4 ? 4 : 1, 0u - ctx->nco_word * (F == 4 ? 4u : 1u),
                                  ctx->in_i16 ? 0x1p-15 : 1.0, tab);
+    }
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * tab_floats);
@@ -208,7 +212,7 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
         return 0;
     }
     // (the NCO's effective complex taps and its per-output phase step, like the single-channel tables)
-    const int bank = ctx->D == 8 ? 8 : 16; // decimation 32 / 64 use the decimate-by-16 tail (its NCO steps are per fs/16 output)
+    const int bank = ctx->D == 8 ? 8 : 16; // (if_fir_channelizer_process_device: decimation 8 or 16 here)
     if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)bank,
                              ctx->in_i16 ? 0x1p-15 : 1.0, tab, bank);
     hipError_t e = hipSetDevice(ctx->device);
@@ -616,36 +620,21 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     a.grid_limit = (fft_var && ctx->variant > 2000 && ctx->variant < 3000) ? ctx->variant - 2000 : 0;
     a.no_fold = ctx->variant == 3000;
 #endif
-    if_fir::ChanArgs own_chan{};
-    if (!chan && ctx->backend == IF_FIR_BACKEND_HIP_FFT && bank_route(ctx) && m > 0)
-    {
-        // single-channel decimate-by-8 / -16: the filter bank with one channel at slot 0 (no mix-down: every phasor is 1)
-        if (!ensure_bank_tables(ctx))
-            return 0;
-        own_chan.count = 1;
-        own_chan.slot[0] = 0;
-        own_chan.out[0] = (float2 *)out;
-        own_chan.sub = ctx->D >= 16 ? (uint32_t)ctx->D / 16u : 1u;
-        for (int k = 0; k < 7; k++)
-            own_chan.tw[0][2 * k] = 1.0f;
-        chan = &own_chan;
-    }
     if (chan)
     {
         // mix-down phase of every channel at this call's first output: exp(-j 2 pi slot (consumed + n0) / 16)
         // (decimation 16: the arrays are indexed by slot, all 16 are filled)
-        const uint32_t entries = ctx->D >= 16 ? 16u : chan->count;
+        const bool slots16 = ctx->D == 16;
+        const uint32_t entries = slots16 ? 16u : chan->count;
         for (uint32_t c = 0; c < entries; c++)
         {
-            const uint32_t slot = ctx->D >= 16 ? c : chan->slot[c];
+            const uint32_t slot = slots16 ? c : chan->slot[c];
             const uint32_t e = (uint32_t)((slot * ((ctx->consumed + n0) & 15u)) & 15u);
             chan->rot0[c][0] = (float)cos(-2.0 * M_PI * (double)e / 16.0);
             chan->rot0[c][1] = (float)sin(-2.0 * M_PI * (double)e / 16.0);
         }
-        if (ctx->D >= 16)
+        if (slots16)
         {
-            if (!chan->sub)
-                chan->sub = 1;
             chan->rot_e = (uint32_t)((ctx->consumed + n0) & 15u);
             chan->mask16 = 0;
             for (uint32_t c = 0; c < 16; c++)

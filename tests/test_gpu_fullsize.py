@@ -61,7 +61,8 @@ def test_full_size_windows_and_split_invariance(fir, oracle, gpu_ok, t, d, log2n
 
 
 @pytest.mark.parametrize("t,d,log2n", [(255, 4, 28), (1023, 1, 28), (127, 1, 26),
-                                       (255, 2, 28), (255, 8, 28), (511, 16, 28), (1023, 32, 28), (255, 64, 28)])
+                                       (255, 2, 28), (255, 8, 28), (511, 16, 28), (1023, 32, 28), (255, 64, 28),
+                                       (255, 12, 28), (255, 24, 28)])
 def test_full_size_fft_backend(fir, oracle, gpu_ok, t, d, log2n):
     """Overlap-save backend (AUTO) at BASELINE sizes: windows of the stream within SPEC tolerance of the float64 oracle,
     and split invariance (one call vs two calls at an odd cut) within tolerance of each other.  Decimations 2, 8, 16, 32

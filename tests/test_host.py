@@ -264,7 +264,8 @@ def test_no_overlap_save_instantiation_spills():
     fft = {k: v for k, v in kernels.items() if "fir_fft_kernel" in k}
     # 5 overlap lengths x (4 + 4 + 4 + 4 single-channel: full rate, decimate-by-4, -by-2, selecting store; 2 + 4 + 4 filter-bank: decimation 4,
     # and 8 / 16 with and without NCO) variants + 8 accumulating ones
-    assert len(fft) == 138, len(fft)
+    # + 20 (round 3): the decimate-by-4 tail keeping every sub-th output (decimation 12, 20, ..., 60)
+    assert len(fft) == 158, len(fft)
     for name, res in fft.items():
         assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
 
