@@ -1169,11 +1169,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 // decimation 8, 12, ..., 64: every sub-th output of the decimate-by-4 tail is a real output.  Descriptor over the
                 // kept outputs from this block's first one on (decn_m of them in the call); a lane that keeps nothing, or an
                 // index beyond the end, is dropped by the bounds check.
-                const unsigned sub = chan.sub;
-                const int64_t qb = (obase + (int64_t)sub - 1) / (int64_t)sub; // wave-uniform
-                const srd_t dsrd = make_srd(out + qb, (diag & 2) ? 0 : (decn_m - qb) * 8);
                 KeepEvery ke;
-                ke.init(blk, (unsigned)LOUT, sub);
+                ke.init(blk, (unsigned)LOUT, chan.sub);
+                const int64_t qb = ke.qU + (ke.rem ? 1 : 0); // ceil(obase / sub): the first kept output of this block, wave-uniform
+                const srd_t dsrd = make_srd(out + qb, (diag & 2) ? 0 : (decn_m - qb) * 8);
                 const int lim = (int)((M - obase) < 65536 ? (M - obase) : 65536); // tail outputs of the call left from this block on
 #pragma unroll
                 for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
@@ -1411,7 +1410,9 @@ bool fft_supported(int T, int D)
 // decimation.  F = 2: decimation 2.  F = 4: decimation 4 and every other multiple of 4 up to 64 -- the decimate-by-4 tail keeping
 // every sub-th output (round 3; measured faster than the one-channel filter-bank tails at 8 / 16 it replaced for single channels,
 // profiles/r03_composite_decimations.txt).  Everything else (odd D, 2 x odd, filters of more than 3073 taps) runs the full-rate
-// kernel with a selecting store.  One definition for the launcher, the shim's tables and the multi-channel front's chunk grid.
+// kernel with a selecting store (2 x odd behind the decimate-by-2 tail was tried: its store path has no registers left for the
+// index arithmetic -- 64 output registers + the next block's rows in flight -- and spilled in 13 instantiations).  One
+// definition for the launcher, the shim's tables and the multi-channel front's chunk grid.
 bool fft_tail(int T, int D, int *pF, int *pSub)
 {
     int F = 1;
