@@ -202,6 +202,20 @@ def test_beyond_32_bit_offsets(fir, oracle, gpu_ok):
             got = y[2 * (start // d):2 * (start // d) + ref.size].cpu().numpy()
             l2, mx = oracle.err_metrics(got, ref)
             assert l2 <= 1e-6 and mx <= 1e-6, (start, l2, mx)
+        # decimation 12 = the same tail keeping every 3rd output (round 3): the very bits of every 3rd decimate-by-4 output, with
+        # block indices up to 2^31 / 3840 in its index arithmetic
+        with fir.IfFir(taps, 12, 0) as f12:
+            m12 = f12.out_count(n)
+            y12 = torch.empty(2 * m12, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            assert f12.process_device(x.data_ptr(), y12.data_ptr(), n) == m12
+            f12.synchronize()
+            yv, y12v = y.view(-1, 2), y12.view(-1, 2)
+            step12 = 1 << 26
+            for a in range(0, m12, step12):
+                b = min(m12, a + step12)
+                assert torch.equal(y12v[a:b], yv[3 * a:3 * b:3]), a
+            del y12, y12v
         f.reset()
         f.set_backend(fir.BACKEND_HIP_DIRECT)
         yd = torch.empty_like(y)

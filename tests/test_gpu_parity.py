@@ -967,6 +967,38 @@ def test_fft_backend_any_decimation(fir, oracle, t, d):
         assert l2 <= TOL and mx <= TOL, ("i16", l2, mx)
 
 
+@pytest.mark.parametrize("i16,nco", [(False, 0.0), (True, 0.0), (False, -0.21), (True, 0.137)])
+def test_multiples_of_4_are_the_decimate_by_4_outputs_thinned(fir, oracle, i16, nco):
+    """Decimation 8, 12, ..., 64 run behind the decimate-by-4 tail and keep every (D/4)-th of its outputs (round 3): from the
+    start of a stream they are, bit for bit, every (D/4)-th output of the decimate-by-4 context -- a whole-array property
+    that needs no oracle -- and within SPEC tolerance of the float64 oracle like everything else."""
+    n = 777_777
+    x = oracle.synth_iq(n, 31)
+    taps = fir.bpf_design(511, 0.0, 0.02)
+    if i16:
+        xin = np.clip(np.round(x * 7000.0), -32768, 32767).astype(np.int16)
+        xf = xin.astype(np.float32) * np.float32(2.0 ** -15)
+    else:
+        xin, xf = x, x
+
+    def run(d):
+        with fir.IfFir(taps, d, n) as f:
+            if i16:
+                f.set_input_format(fir.INPUT_I16)
+            if nco:
+                f.set_nco(nco)
+            assert f.get_backend() == fir.BACKEND_HIP_FFT
+            return f.process(xin)
+    y4 = run(4).reshape(-1, 2)
+    for d in range(8, 65, 4):
+        yd = run(d).reshape(-1, 2)
+        assert yd.shape[0] == oracle.out_count(0, n, d)
+        assert np.array_equal(yd, y4[::d // 4][:yd.shape[0]]), d
+    ref = oracle.fir_nco_f64(taps, xf, 20, oracle.nco_phase_word(nco)) if nco else oracle.fir_f64(taps, xf, 20)
+    l2, mx = oracle.err_metrics(run(20), ref)
+    assert l2 <= TOL and mx <= TOL, (l2, mx)
+
+
 def test_uniform_filter_bank_int16_input(fir, oracle, torch_cuda):
     """The filter bank straight on an int16 SDR stream (both halves of §8f-1 and §8f-2 together)."""
     torch = torch_cuda

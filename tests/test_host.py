@@ -304,3 +304,28 @@ def test_bench_line_contract_on_the_committed_run():
     n = d["config"]["samples_per_channel"] * d["config"].get("channels", d["n_gpus"])
     assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
     assert d["parity"]["whole_output"]["ok"] is True
+
+
+def test_keep_every_index_arithmetic_of_the_decimating_tail():
+    """Decimation 8, 12, ..., 64 run behind the decimate-by-4 tail, which keeps every sub-th of its outputs
+    (csrc/if_fir_fft.hip, KeepEvery).  Its integer arithmetic, restated here, against plain division over the whole range
+    the kernel can see: the block's share blk * lout divided in 32-bit pieces (blk < 2^31), and the per-output
+    multiply-shift by ceil(2^18 / sub) for every numerator remainder + lane + 64 * row that can occur."""
+    rng = np.random.default_rng(5)
+    for sub in range(2, 17):
+        magic = (262144 + sub - 1) // sub
+        u = np.arange(0, 16 + 64 + 64 * 15 + 1, dtype=np.uint64)
+        assert np.array_equal((u * np.uint64(magic)) >> np.uint64(18), u // np.uint64(sub)), sub
+        assert int(u.max()) * magic < 2 ** 32        # the product stays in 32 bits
+        for lout in (960, 896, 768, 512, 256):       # outputs of the decimate-by-4 tail per block: (4096 - 64 rows) / 4
+            blks = np.concatenate([np.arange(0, 70), rng.integers(0, 2 ** 31, 2000), [2 ** 31 - 1]]).astype(np.uint64)
+            for blk in blks:
+                blk = int(blk)
+                if sub & (sub - 1) == 0:
+                    q, rem = (blk * lout) >> (sub.bit_length() - 1), (blk * lout) & (sub - 1)
+                else:
+                    bq, br = (blk & 0xffffffff) // sub, (blk & 0xffffffff) % sub
+                    t = (br * lout) & 0xffffffff
+                    q2 = t // sub
+                    q, rem = bq * lout + q2, t - q2 * sub
+                assert (q, rem) == divmod(blk * lout, sub), (sub, lout, blk)
