@@ -13,7 +13,7 @@
  *                  stores, 16 every wave fetches the same block, 32 static block map, 64 one wave per SIMD
  *   1000000 + bits the same with room for more bits (round 3): 4 + (n << 12) late start of the second wave per SIMD,
  *                  8 / 128 cache-line touches ahead of the next block group, ...  
- *   3000           decimation 2 through the full-rate kernel + selecting store instead of its decimating tail (same results to
+ *   3000           decimation 2, 6, 10, ..., 62 through the full-rate kernel + selecting store instead of the decimate-by-2 tail (same results to
  *                  tolerance; A/B timing)
  *   4000           the next call fails before anything is launched (IF_FIR_DEBUG=1): lets tests reach callers' error paths
  * Environment (dev library only): IF_FIR_DEBUG=1 IF_FIR_VARIANT=n preselects a variant at if_fir_init.

@@ -309,7 +309,7 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
     __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, IF_FIR_FFT_STORE_AUX);
 }
 
-// Decimations D = 4 * sub (8, 12, ..., 64) behind the decimate-by-4 tail: the tail
+// Decimations D = 4 * sub (8, 12, ..., 64) behind the decimate-by-4 tail, D = 2 * sub (6, 10, ..., 62) behind the decimate-by-2 one: the tail
 // runs at the fs/F rate and every sub-th of its outputs is a real output.  The block grid starts at a kept output (the launcher
 // shifts it by the call's decimation phase), so tail output number i (counted over the whole call) is kept when i is a
 // multiple of sub, as output i / sub.  The block's share (obase) is divided once per block, wave-uniform, in SGPRs; each
@@ -477,15 +477,17 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
     // CHAN names the decimating tail beyond the plain decimate-by-4 one: 2 = single channel, decimation 2 (frequency-domain
     // fold + 2048-point inverse); 4 / 8 / 16 = the filter bank at that decimation
-    // (1 = the decimate-by-4 tail keeping every sub-th output: decimation 8, 12, ..., 64)
-    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4), "decimating tails: 1, 2, or the bank at 4, 8, 16");
+    // (1 = the decimate-by-4 tail keeping every sub-th output: decimation 8, 12, ..., 64; 3 = the decimate-by-2 tail doing the same:
+    // decimation 6, 10, ..., 62)
+    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4),
+                  "decimating tails: 1, 2, 3, or the bank at 4, 8, 16");
     static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
     const char *in = reinterpret_cast<const char *>(in_);
     constexpr int L = FFT_N - OVL;         // new input samples per block
-    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : CHAN == 2 ? L / 2 : DEC4 ? L / 4 : L; // outputs per block (per channel)
+    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L; // outputs per block (per channel)
     constexpr int EARLY_GROUPS = IF_FIR_FFT_EARLY_GROUPS; // dec4: batches of next-block loads issued during pass 3
     constexpr int LAUX = IF_FIR_FFT_LOAD_AUX(OVL_ROWS); // cache policy of the row loads
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 }
             }
         }
-        else if constexpr (CHAN == 2)
+        else if constexpr (CHAN == 2 || CHAN == 3)
         {
             // ---- decimate-by-2 tail (round 3): pass 3, multiply by H/4096, fold the 2 aliases
             // (k2 = k2' + 8 j) in place: r[phys(i, k2')] = z(i, k2'), k2' = 0..7; the other 8 registers of the group are dead
@@ -913,6 +915,28 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     co[mu0] = cmul_v<false>(co[mu0], cmul_v<false>(a_odd, ncob[4 * (mu0 - MU0_FIRST)]));
                 }
             }
+            if constexpr (CHAN == 3)
+            {
+                // decimation 6, 10, ..., 62 (2 x odd): every sub-th output of this tail is a real output (KeepEvery, as behind the
+                // decimate-by-4 tail); the pair of a lane never survives together, so two 8-byte stores with their own offsets.
+                // The index arithmetic needs registers: the other half of the next block's rows is requested BEHIND the stores here.
+                KeepEvery ke;
+                ke.init(blk, (unsigned)LOUT, chan.sub);
+                const int64_t qb = ke.qU + (ke.rem ? 1 : 0);
+                const srd_t dsrd = make_srd(out + qb, (diag & 2) ? 0 : (decn_m - qb) * 8);
+                const int lim = (int)((M - obase) < 65536 ? (M - obase) : 65536); // tail outputs of the call left from this block on
+                int off = 2 * lane;
+#pragma unroll
+                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                {
+                    // (one running offset, made opaque: otherwise the 30 store offsets are computed ahead of the inverses and spill)
+                    asm volatile("" : "+v"(off));
+                    const int64_t k0 = ke.index((unsigned)off), k1 = ke.index((unsigned)off + 1u);
+                    buf_store(dsrd, (k0 >= 0 && off < lim) ? (unsigned)(k0 - qb) * 8u : 0xffffffffu, 0, ce[mu0]);
+                    buf_store(dsrd, (k1 >= 0 && off + 1 < lim) ? (unsigned)(k1 - qb) * 8u : 0xffffffffu, 0, co[mu0]);
+                    off += 128;
+                }
+            }
             if (next_fast) // the other half of the next block's rows
             {
 #pragma unroll
@@ -922,6 +946,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
             }
             unsigned vo128 = (unsigned)lane * 16u;
+            if constexpr (CHAN == 2)
+            {
 #pragma unroll
             for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
             {
@@ -936,6 +962,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 vo128 += 1024u;
                 asm volatile("" : "+v"(vo128)); // one running offset register, not 15 precomputed ones
             }
+            }
+            (void)vo128;
         }
         else if constexpr (CHAN == 8)
         {
@@ -1344,7 +1372,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 {
     auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN, ACC>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
-    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : CHAN == 2 ? L / 2 : DEC4 ? L / 4 : L;
+    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L;
     static DeviceSetup setup;
     int ncus = 0;
     {
@@ -1355,9 +1383,9 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     // DECN: the kernel runs at full rate over the N inputs (blocks, run queue, history as for D = 1) and keeps every
     // D-th output, the first one at full-rate index n0
     // (decimation 4 sub behind the decimate-by-4 tail, CHAN == 1: the tail runs at the fs/4 rate and keeps every sub-th output)
-    constexpr int F = CHAN == 16 ? 16 : CHAN == 8 ? 8 : CHAN == 2 ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
+    constexpr int F = CHAN == 16 ? 16 : CHAN == 8 ? 8 : (CHAN == 2 || CHAN == 3) ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
     ChanArgs ca = a.chan ? *a.chan : ChanArgs{};
-    ca.sub = CHAN == 1 ? (uint32_t)(a.D / 4) : 1u;
+    ca.sub = CHAN == 1 ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : 1u;
     const int64_t m_rate = DECN ? a.N : (a.M - 1) * (int64_t)ca.sub + 1;
     const int32_t n0_rate = DECN ? 0 : a.n0;
     const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
@@ -1406,18 +1434,17 @@ bool fft_supported(int T, int D)
     return D >= 1 && D <= 64 && T >= 1 && T <= 4096;
 }
 
-// Which decimations have a decimating tail (frequency-domain alias fold + small inverse): D = F * sub with F the tail's own
-// decimation.  F = 2: decimation 2.  F = 4: decimation 4 and every other multiple of 4 up to 64 -- the decimate-by-4 tail keeping
-// every sub-th output (round 3; measured faster than the one-channel filter-bank tails at 8 / 16 it replaced for single channels,
-// profiles/r03_composite_decimations.txt).  Everything else (odd D, 2 x odd, filters of more than 3073 taps) runs the full-rate
-// kernel with a selecting store (2 x odd behind the decimate-by-2 tail was tried: its store path has no registers left for the
-// index arithmetic -- 64 output registers + the next block's rows in flight -- and spilled in 13 instantiations).  One
-// definition for the launcher, the shim's tables and the multi-channel front's chunk grid.
+// Which decimations have a decimating tail (frequency-domain alias fold + small inverse): every EVEN one, D = F * sub with F the
+// tail's own decimation.  F = 4: decimation 4 and every other multiple of 4 up to 64 -- the decimate-by-4 tail keeping every
+// sub-th output (round 3; measured faster than the one-channel filter-bank tails at 8 / 16 it replaced for single channels,
+// profiles/r03_composite_decimations.txt).  F = 2: decimation 2, and 6, 10, ..., 62 the same way behind the decimate-by-2 tail.
+// Odd decimations and filters of more than 3073 taps run the full-rate kernel with a selecting store.  One definition for
+// the launcher, the shim's tables and the multi-channel front's chunk grid.
 bool fft_tail(int T, int D, int *pF, int *pSub)
 {
     int F = 1;
     if (D >= 1 && D <= 64 && T >= 1 && T <= 3073)
-        F = (D == 2) ? 2 : (D % 4 == 0) ? 4 : 1;
+        F = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
     if (pF)
         *pF = F;
     if (pSub)
@@ -1485,6 +1512,14 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
         case 1: return launch_fft_t<ROWS, true, false, true>(a);
         case 2: return launch_fft_t<ROWS, true, true, false>(a);
         default: return launch_fft_t<ROWS, true, true, true>(a);
+        }
+    if (tail && F == 2 && !a.no_fold) // decimation 6, 10, ..., 62: the decimate-by-2 tail keeping every sub-th output
+        switch (key)
+        {
+        case 0: return launch_fft_t<ROWS, true, false, false, 3>(a);
+        case 1: return launch_fft_t<ROWS, true, false, true, 3>(a);
+        case 2: return launch_fft_t<ROWS, true, true, false, 3>(a);
+        default: return launch_fft_t<ROWS, true, true, true, 3>(a);
         }
     if (tail && F == 4) // decimation 8, 12, ..., 64: the decimate-by-4 tail keeping every sub-th output (tables as for decimation 4)
         switch (key)

@@ -520,6 +520,7 @@ def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
              (2047, 4, 600_003, 1_000_008), (255, 4, 600_002, 1_000_008), (255, 4, 600_001, 1_000_007),
              (255, 7, 600_003, 1_000_008), (3075, 4, 600_001, 1_000_008), (255, 8, 600_003, 1_000_008), (255, 2, 600_001, 1_000_008), (255, 32, 600_007, 1_000_008),
              (1023, 16, 600_005, 1_000_008), (255, 12, 600_005, 1_000_008), (255, 24, 600_007, 1_000_008), (1023, 40, 600_011, 1_000_008),
+             (255, 6, 600_001, 1_000_008), (511, 10, 600_003, 1_000_008),
              (255, 11, 2_500_003, 7_400_000)]
     for t, d, first, n in cases:
         cuts = [0, first, n]
@@ -916,14 +917,14 @@ def test_contexts_on_concurrent_threads(fir, oracle):
 @pytest.mark.parametrize("t,d", [(255, 2), (255, 3), (1023, 8), (63, 5), (257, 16), (1025, 64), (255, 7), (255, 8), (2047, 16),
                                  (3073, 8), (1023, 2), (2047, 2), (3073, 2), (31, 2), (255, 32), (1023, 32), (127, 64), (3073, 64),
                                  (255, 12), (1023, 20), (255, 24), (513, 28), (2047, 40), (255, 48), (3073, 56), (255, 60), (127, 44),
-                                 (3073, 12), (255, 6), (3075, 12)])
+                                 (3073, 12), (255, 6), (3075, 12), (1023, 10), (255, 62), (513, 14), (3073, 30), (3075, 6)])
 def test_fft_backend_any_decimation(fir, oracle, t, d):
     """Decimations other than 1 and 4 on the overlap-save backend: the full-rate kernel keeps every D-th output (one
     64-bit division per block and lane, an exact multiply-shift per row); decimation 2 (frequency-domain fold + 2048-point
     inverse) and 8 / 16 / 32 / 64 (the one-channel filter-bank route; 32 and 64 keep every 2nd / 4th output of the
     decimate-by-16 tail) have their own tails since round 3 (development variant 3000 = the selecting store for them too); so
     have the multiples of 4 and 8 (12, 20, ..., 60 behind the decimate-by-4 tail, 24, 40, 48, 56 behind the decimate-by-8 one: the
-    tail keeps every 3rd, 5th, ... output).  One
+    tail keeps every 3rd, 5th, ... output), and 6, 10, ..., 62 behind the decimate-by-2 tail: every even decimation has a tail.  One
     call, ragged pieces (every decimation phase at a call boundary), the run queue on a one-workgroup grid, NCO (always
     the selecting store) and int16 input on top."""
     rng = np.random.default_rng(7000 + t + d)
@@ -969,7 +970,8 @@ def test_fft_backend_any_decimation(fir, oracle, t, d):
 
 @pytest.mark.parametrize("i16,nco", [(False, 0.0), (True, 0.0), (False, -0.21), (True, 0.137)])
 def test_multiples_of_4_are_the_decimate_by_4_outputs_thinned(fir, oracle, i16, nco):
-    """Decimation 8, 12, ..., 64 run behind the decimate-by-4 tail and keep every (D/4)-th of its outputs (round 3): from the
+    """Decimation 8, 12, ..., 64 run behind the decimate-by-4 tail and keep every (D/4)-th of its outputs (round 3; 6, 10, ..., 62
+    likewise behind the decimate-by-2 tail): from the
     start of a stream they are, bit for bit, every (D/4)-th output of the decimate-by-4 context -- a whole-array property
     that needs no oracle -- and within SPEC tolerance of the float64 oracle like everything else."""
     n = 777_777
@@ -994,6 +996,11 @@ def test_multiples_of_4_are_the_decimate_by_4_outputs_thinned(fir, oracle, i16, 
         yd = run(d).reshape(-1, 2)
         assert yd.shape[0] == oracle.out_count(0, n, d)
         assert np.array_equal(yd, y4[::d // 4][:yd.shape[0]]), d
+    y2 = run(2).reshape(-1, 2)      # 6, 10, ..., 62: every (D/2)-th output of the decimate-by-2 tail
+    for d in range(6, 63, 4):
+        yd = run(d).reshape(-1, 2)
+        assert yd.shape[0] == oracle.out_count(0, n, d)
+        assert np.array_equal(yd, y2[::d // 2][:yd.shape[0]]), d
     ref = oracle.fir_nco_f64(taps, xf, 20, oracle.nco_phase_word(nco)) if nco else oracle.fir_f64(taps, xf, 20)
     l2, mx = oracle.err_metrics(run(20), ref)
     assert l2 <= TOL and mx <= TOL, (l2, mx)

@@ -264,8 +264,8 @@ def test_no_overlap_save_instantiation_spills():
     fft = {k: v for k, v in kernels.items() if "fir_fft_kernel" in k}
     # 5 overlap lengths x (4 + 4 + 4 + 4 single-channel: full rate, decimate-by-4, -by-2, selecting store; 2 + 4 + 4 filter-bank: decimation 4,
     # and 8 / 16 with and without NCO) variants + 8 accumulating ones
-    # + 20 (round 3): the decimate-by-4 tail keeping every sub-th output (decimation 12, 20, ..., 60)
-    assert len(fft) == 158, len(fft)
+    # + 20 + 20 (round 3): the decimate-by-4 / -by-2 tails keeping every sub-th output (decimation 8, 12, ..., 64 / 6, 10, ..., 62)
+    assert len(fft) == 178, len(fft)
     for name, res in fft.items():
         assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
 
@@ -312,12 +312,12 @@ def test_keep_every_index_arithmetic_of_the_decimating_tail():
     the kernel can see: the block's share blk * lout divided in 32-bit pieces (blk < 2^31), and the per-output
     multiply-shift by ceil(2^18 / sub) for every numerator remainder + lane + 64 * row that can occur."""
     rng = np.random.default_rng(5)
-    for sub in range(2, 17):
+    for sub in range(2, 32):    # up to 16 behind the decimate-by-4 tail, odd ones up to 31 behind the decimate-by-2 tail
         magic = (262144 + sub - 1) // sub
-        u = np.arange(0, 16 + 64 + 64 * 15 + 1, dtype=np.uint64)
+        u = np.arange(0, 32 + 128 + 128 * 15 + 1, dtype=np.uint64)  # remainder + lane offset (2 per lane + 1) + row step
         assert np.array_equal((u * np.uint64(magic)) >> np.uint64(18), u // np.uint64(sub)), sub
         assert int(u.max()) * magic < 2 ** 32        # the product stays in 32 bits
-        for lout in (960, 896, 768, 512, 256):       # outputs of the decimate-by-4 tail per block: (4096 - 64 rows) / 4
+        for lout in (960, 896, 768, 512, 256, 1920, 1792, 1536, 1024):   # tail outputs per block: (4096 - 64 rows) / 4 or / 2
             blks = np.concatenate([np.arange(0, 70), rng.integers(0, 2 ** 31, 2000), [2 ** 31 - 1]]).astype(np.uint64)
             for blk in blks:
                 blk = int(blk)

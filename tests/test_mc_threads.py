@@ -28,7 +28,7 @@ def test_ranks_as_threads_match_single_channel_contexts(fake_rccl, world, channe
     assert "bit-identical" in run.stdout
 
 
-@pytest.mark.parametrize("d", [2, 3, 4, 7, 8, 12, 16, 24, 32])
+@pytest.mark.parametrize("d", [2, 3, 4, 6, 7, 8, 12, 16, 24, 32])
 def test_ranks_as_threads_off_phase_chunks(fake_rccl, d):
     """call lengths that leave the decimation phase != 0, chunked (215040-sample chunks, two slots of staging
     per owned channel on the ranks other than 0): every channel bit-identical to an unchunked single-channel context."""
