@@ -13,6 +13,11 @@
 // Index algebra: tools/fft_model.py (checked against numpy.fft).  No workgroup barriers after the table load: the 8
 // waves of a 512-thread workgroup are independent; FFT blocks are handed out through an atomic queue.
 // FP32 VALU only (v_add/v_fma/v_pk_*), no MFMA.
+//
+// Build: this file is compiled six times (csrc/Makefile) -- once per overlap length with -DIF_FIR_FFT_ROWS=4|8|16|32|48 (the
+// kernel, its launcher and the explicit instantiation of launch_fft_rows<ROWS>; the 32-row unit also carries the two-partition
+// launches) and once without it (host side: tables, routing predicates, launch_fft) -- so that the 178 instantiations compile
+// in parallel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -155,6 +160,7 @@ __device__ __forceinline__ constexpr int phys(int i, int j)
 }
 
 constexpr int FFT_N = 4096;
+constexpr int FFT_PART = 2048; // filters of 3074..4096 taps: two partitions of at most this many taps
 constexpr int XROW = 136;             // bytes per 16-entry row of the exchange buffers (16*8 + 8 pad)
 constexpr int XREG = 16 * XROW + 32;  // one 16x16 region (+32 so that the 4 regions start on different banks)
 constexpr int XBUF = 4 * XREG;        // per-wave exchange buffer
@@ -462,6 +468,7 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
     inverse_tail256(a, c, twe, xb, lane);
 }
 
+#ifdef IF_FIR_FFT_ROWS // ================= kernel + launcher: the per-overlap-length compilation units =================
 template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, int CHAN, bool DECN, bool ACC>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
@@ -1350,6 +1357,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #endif
 }
 
+#endif // IF_FIR_FFT_ROWS
+#ifndef IF_FIR_FFT_ROWS // ================= host side =================
 // Host view of the block queue (see queue_take): groups of FFT_WAVES blocks in global order; workgroup b starts with
 // global group b (static), every further group of a workgroup is global group wgs + ticket.  Tickets keep being drawn
 // past the end (a wave learns that it is done by receiving a block >= nblocks), at most one per group slot 0 taken, so a
@@ -1367,6 +1376,8 @@ void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s)
     s.tickets = groups + 2 * s.wgs; // upper bound of the counter at the end of the launch
 }
 
+#endif
+#ifdef IF_FIR_FFT_ROWS
 template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, int CHAN = 0, bool DECN = false, bool ACC = false>
 static hipError_t launch_fft_t(const LaunchArgs &a)
 {
@@ -1426,6 +1437,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     return le;
 }
 
+#endif // IF_FIR_FFT_ROWS
+#ifndef IF_FIR_FFT_ROWS
 // D = 1 and D = 4 have their own kernels; any other decimation runs the full-rate kernel with a selecting store.
 // Taps: the first T-1 outputs of a 4096-point block are discarded, in whole 64-sample rows (4, 8, 16, 32 or 48 of the
 // 64): up to 257 taps cost 6 % of the block, 513 taps 12.5 %, 1025 taps 25 %, 2049 taps half, 3073 taps three quarters.
@@ -1453,7 +1466,6 @@ bool fft_tail(int T, int D, int *pF, int *pSub)
 }
 
 // 3074..4096 taps: two partitions of at most FFT_PART taps each, y = h_a * x + h_b * (x delayed by FFT_PART)
-constexpr int FFT_PART = 2048;
 bool fft_two_partitions(int T)
 {
     return T > 3073;
@@ -1466,8 +1478,13 @@ int fft_overlap_rows(int T)
     return (T - 1 <= 256) ? 4 : (T - 1 <= 512) ? 8 : (T - 1 <= 1024) ? 16 : (T - 1 <= 2048) ? 32 : 48;
 }
 
+#endif
 template <int ROWS>
-static hipError_t launch_fft_rows(const LaunchArgs &a)
+hipError_t launch_fft_rows(const LaunchArgs &a); // defined and explicitly instantiated in the unit compiled with IF_FIR_FFT_ROWS = ROWS
+hipError_t launch_fft_two_partitions(const LaunchArgs &a); // (in the 32-row unit)
+#ifdef IF_FIR_FFT_ROWS
+template <int ROWS>
+hipError_t launch_fft_rows(const LaunchArgs &a)
 {
     int F = 1;
     const bool tail = fft_tail(a.T, a.D, &F, nullptr);
@@ -1546,6 +1563,9 @@ static hipError_t launch_fft_rows(const LaunchArgs &a)
     }
 }
 
+template hipError_t launch_fft_rows<IF_FIR_FFT_ROWS>(const LaunchArgs &a);
+
+#if IF_FIR_FFT_ROWS == 32
 // second partition: input delayed by FFT_PART samples, table B, accumulate into the outputs of the first launch
 static hipError_t launch_fft_acc(const LaunchArgs &a)
 {
@@ -1567,45 +1587,51 @@ static hipError_t launch_fft_acc(const LaunchArgs &a)
     }
 }
 
+// Filters of 3074..4096 taps: h = (h_a, h_b) with 2048 taps in h_a.  Launch 1: y = h_a * x (writes the history);
+// launch 2: y += h_b * x(n - 2048).  Both are the 32-row (2049-tap) kernel at full rate; a decimation other than 1
+// (4 included) goes through the selecting store.  The history holds 4096 samples: 2048 of delay + the overlap.
+hipError_t launch_fft_two_partitions(const LaunchArgs &a)
+{
+    if (a.chan || !a.fft_tables_b || a.hist_len < 2 * FFT_PART)
+        return hipErrorInvalidConfiguration;
+    LaunchArgs p = a;
+    p.T = FFT_PART;
+    const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
+    hipError_t e;
+    if (a.D == 1)
+        switch (key)
+        {
+        case 0: e = launch_fft_t<32, false, false, false>(p); break;
+        case 1: e = launch_fft_t<32, false, false, true>(p); break;
+        case 2: e = launch_fft_t<32, false, true, false>(p); break;
+        default: e = launch_fft_t<32, false, true, true>(p); break;
+        }
+    else
+        switch (key)
+        {
+        case 0: e = launch_fft_t<32, false, false, false, false, true>(p); break;
+        case 1: e = launch_fft_t<32, false, false, true, false, true>(p); break;
+        case 2: e = launch_fft_t<32, false, true, false, false, true>(p); break;
+        default: e = launch_fft_t<32, false, true, true, false, true>(p); break;
+        }
+    if (e != hipSuccess)
+        return e;
+    p.T = a.T - FFT_PART;
+    p.fft_tables = a.fft_tables_b;
+    p.in_shift = FFT_PART;
+    p.hist_out = nullptr; // the first launch wrote the next history
+    return launch_fft_acc(p);
+}
+#endif // 32-row unit
+#endif // IF_FIR_FFT_ROWS
+
+#ifndef IF_FIR_FFT_ROWS
 hipError_t launch_fft(const LaunchArgs &a)
 {
     if (!fft_supported(a.T, a.D) || !a.fft_tables)
         return hipErrorInvalidConfiguration;
     if (fft_two_partitions(a.T))
-    {
-        // Filters of 3074..4096 taps: h = (h_a, h_b) with 2048 taps in h_a.  Launch 1: y = h_a * x (writes the history);
-        // launch 2: y += h_b * x(n - 2048).  Both are the 32-row (2049-tap) kernel at full rate; a decimation other than 1
-        // (4 included) goes through the selecting store.  The history holds 4096 samples: 2048 of delay + the overlap.
-        if (a.chan || !a.fft_tables_b || a.hist_len < 2 * FFT_PART)
-            return hipErrorInvalidConfiguration;
-        LaunchArgs p = a;
-        p.T = FFT_PART;
-        const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
-        hipError_t e;
-        if (a.D == 1)
-            switch (key)
-            {
-            case 0: e = launch_fft_t<32, false, false, false>(p); break;
-            case 1: e = launch_fft_t<32, false, false, true>(p); break;
-            case 2: e = launch_fft_t<32, false, true, false>(p); break;
-            default: e = launch_fft_t<32, false, true, true>(p); break;
-            }
-        else
-            switch (key)
-            {
-            case 0: e = launch_fft_t<32, false, false, false, false, true>(p); break;
-            case 1: e = launch_fft_t<32, false, false, true, false, true>(p); break;
-            case 2: e = launch_fft_t<32, false, true, false, false, true>(p); break;
-            default: e = launch_fft_t<32, false, true, true, false, true>(p); break;
-            }
-        if (e != hipSuccess)
-            return e;
-        p.T = a.T - FFT_PART;
-        p.fft_tables = a.fft_tables_b;
-        p.in_shift = FFT_PART;
-        p.hist_out = nullptr; // the first launch wrote the next history
-        return launch_fft_acc(p);
-    }
+        return launch_fft_two_partitions(a);
     switch (fft_overlap_rows(a.T))
     {
     case 4: return launch_fft_rows<4>(a);
@@ -1776,5 +1802,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                     hp[2 * ((i * 16 + 4 * m0 + q) * 64 + lane) + 1] = (float)im;
                 }
 }
+
+#endif // host side
 
 } // namespace if_fir
