@@ -16,7 +16,7 @@
 //
 // Build: this file is compiled six times (csrc/Makefile) -- once per overlap length with -DIF_FIR_FFT_ROWS=4|8|16|32|48 (the
 // kernel, its launcher and the explicit instantiation of launch_fft_rows<ROWS>; the 32-row unit also carries the two-partition
-// launches) and once without it (host side: tables, routing predicates, launch_fft) -- so that the 178 instantiations compile
+// launches) and once without it (host side: tables, routing predicates, launch_fft) -- so that the 194 instantiations compile
 // in parallel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -480,7 +480,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 {
     // ACC (filters of 3074..4096 taps, two partitions of <= 2048 taps): this launch filters the input DELAYED by in_shift
     // samples with the second partition's table and adds its result to what the first launch stored
-    static_assert(!ACC || (!DEC4 && !CHAN && OVL_ROWS == 32), "accumulating store: full-rate pipeline, 32 overlap rows");
+    // (round 3: also behind the single-channel decimating tails, CHAN 0..3, so that two-partition filters decimate in the
+    // frequency domain like shorter ones)
+    static_assert(!ACC || (CHAN <= 3 && OVL_ROWS == 32), "accumulating store: single-channel pipelines, 32 overlap rows");
     static_assert(!DECN || (!DEC4 && !CHAN), "general decimation = the full-rate pipeline with a selecting store");
     // CHAN names the decimating tail beyond the plain decimate-by-4 one: 2 = single channel, decimation 2 (frequency-domain
     // fold + 2048-point inverse); 4 / 8 / 16 = the filter bank at that decimation
@@ -939,8 +941,15 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     // (one running offset, made opaque: otherwise the 30 store offsets are computed ahead of the inverses and spill)
                     asm volatile("" : "+v"(off));
                     const int64_t k0 = ke.index((unsigned)off), k1 = ke.index((unsigned)off + 1u);
-                    buf_store(dsrd, (k0 >= 0 && off < lim) ? (unsigned)(k0 - qb) * 8u : 0xffffffffu, 0, ce[mu0]);
-                    buf_store(dsrd, (k1 >= 0 && off + 1 < lim) ? (unsigned)(k1 - qb) * 8u : 0xffffffffu, 0, co[mu0]);
+                    const unsigned so0 = (k0 >= 0 && off < lim) ? (unsigned)(k0 - qb) * 8u : 0xffffffffu;
+                    const unsigned so1 = (k1 >= 0 && off + 1 < lim) ? (unsigned)(k1 - qb) * 8u : 0xffffffffu;
+                    if constexpr (ACC) // second partition: add to what the first launch stored (a dropped lane reads 0)
+                    {
+                        ce[mu0] += buf_load(dsrd, so0, 0);
+                        co[mu0] += buf_load(dsrd, so1, 0);
+                    }
+                    buf_store(dsrd, so0, 0, ce[mu0]);
+                    buf_store(dsrd, so1, 0, co[mu0]);
                     off += 128;
                 }
             }
@@ -959,6 +968,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
             {
                 typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+                if constexpr (ACC) // second partition: add to what the first launch stored
+                {
+                    const u32x4s_t old = __builtin_amdgcn_raw_buffer_load_b128(osrd, vo128, 0, 0);
+                    ce[mu0] += (cf){__uint_as_float(old[0]), __uint_as_float(old[1])};
+                    co[mu0] += (cf){__uint_as_float(old[2]), __uint_as_float(old[3])};
+                }
                 const u32x4s_t w = {__float_as_uint(ce[mu0].x), __float_as_uint(ce[mu0].y), __float_as_uint(co[mu0].x),
                                     __float_as_uint(co[mu0].y)};
                 // The row offset goes into the VECTOR offset, the scalar offset stays the literal 0: with a 16-byte store whose
@@ -1214,6 +1229,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
                     const int64_t kept = ke.index((unsigned)lane + 64u * (unsigned)(mu0 - MU0_FIRST));
                     const unsigned so = (kept >= 0 && lane + 64 * (mu0 - MU0_FIRST) < lim) ? (unsigned)(kept - qb) * 8u : 0xffffffffu;
+                    if constexpr (ACC) // second partition: add to what the first launch stored (a dropped lane reads 0)
+                        c[mu0] += buf_load(dsrd, so, 0);
                     buf_store(dsrd, so, 0, c[mu0]);
                 }
             }
@@ -1221,7 +1238,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             {
 #pragma unroll
                 for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                {
+                    if constexpr (ACC) // second partition: add to what the first launch stored
+                        c[mu0] += buf_load(osrd, voff, (mu0 - MU0_FIRST) * 512);
                     buf_store(osrd, voff, (mu0 - MU0_FIRST) * 512, c[mu0]);
+                }
             }
         }
         else
@@ -1451,12 +1472,13 @@ bool fft_supported(int T, int D)
 // tail's own decimation.  F = 4: decimation 4 and every other multiple of 4 up to 64 -- the decimate-by-4 tail keeping every
 // sub-th output (round 3; measured faster than the one-channel filter-bank tails at 8 / 16 it replaced for single channels,
 // profiles/r03_composite_decimations.txt).  F = 2: decimation 2, and 6, 10, ..., 62 the same way behind the decimate-by-2 tail.
-// Odd decimations and filters of more than 3073 taps run the full-rate kernel with a selecting store.  One definition for
-// the launcher, the shim's tables and the multi-channel front's chunk grid.
+// Odd decimations run the full-rate kernel with a selecting store.  Filters of 3074..4096 taps (two partitions) take the same
+// tails, the second partition accumulating.  One definition for the launcher, the shim's tables and the multi-channel
+// front's chunk grid.
 bool fft_tail(int T, int D, int *pF, int *pSub)
 {
     int F = 1;
-    if (D >= 1 && D <= 64 && T >= 1 && T <= 3073)
+    if (D >= 1 && D <= 64 && T >= 1 && T <= 4096)
         F = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
     if (pF)
         *pF = F;
@@ -1566,61 +1588,51 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
 template hipError_t launch_fft_rows<IF_FIR_FFT_ROWS>(const LaunchArgs &a);
 
 #if IF_FIR_FFT_ROWS == 32
-// second partition: input delayed by FFT_PART samples, table B, accumulate into the outputs of the first launch
-static hipError_t launch_fft_acc(const LaunchArgs &a)
+// Filters of 3074..4096 taps: h = (h_a, h_b) with 2048 taps in h_a.  Launch 1: y = h_a * x (writes the history);
+// launch 2: y += h_b * x(n - 2048): the same kernel with h_b's table, reading the input FFT_PART samples late and adding
+// its result to what launch 1 stored (ACC).  Both are the 32-row (2049-tap) kernel; an even decimation runs behind the
+// decimating tails like shorter filters do (round 3), an odd one through the selecting store.  The history holds 4096
+// samples: 2048 of delay + the overlap.
+template <bool ACC>
+static hipError_t launch_fft_partition(const LaunchArgs &a)
 {
+    int F = 1;
+    (void)fft_tail(a.T, a.D, &F, nullptr); // (a.T: the whole filter's tap count)
     const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
-    if (a.D == 1)
-        switch (key)
-        {
-        case 0: return launch_fft_t<32, false, false, false, false, false, true>(a);
-        case 1: return launch_fft_t<32, false, false, true, false, false, true>(a);
-        case 2: return launch_fft_t<32, false, true, false, false, false, true>(a);
-        default: return launch_fft_t<32, false, true, true, false, false, true>(a);
-        }
-    switch (key)
-    {
-    case 0: return launch_fft_t<32, false, false, false, false, true, true>(a);
-    case 1: return launch_fft_t<32, false, false, true, false, true, true>(a);
-    case 2: return launch_fft_t<32, false, true, false, false, true, true>(a);
-    default: return launch_fft_t<32, false, true, true, false, true, true>(a);
+#define IF_FIR_PART_SWITCH(DEC4, CHAN, DECN)                                            \
+    switch (key)                                                                       \
+    {                                                                                  \
+    case 0: return launch_fft_t<32, DEC4, false, false, CHAN, DECN, ACC>(a);           \
+    case 1: return launch_fft_t<32, DEC4, false, true, CHAN, DECN, ACC>(a);            \
+    case 2: return launch_fft_t<32, DEC4, true, false, CHAN, DECN, ACC>(a);            \
+    default: return launch_fft_t<32, DEC4, true, true, CHAN, DECN, ACC>(a);            \
     }
+    if (a.D == 1)
+        IF_FIR_PART_SWITCH(false, 0, false)
+    if (F == 4 && a.D == 4)
+        IF_FIR_PART_SWITCH(true, 0, false)
+    if (F == 4)
+        IF_FIR_PART_SWITCH(true, 1, false)
+    if (F == 2 && a.D == 2 && !a.no_fold)
+        IF_FIR_PART_SWITCH(true, 2, false)
+    if (F == 2 && !a.no_fold)
+        IF_FIR_PART_SWITCH(true, 3, false)
+    IF_FIR_PART_SWITCH(false, 0, true)
+#undef IF_FIR_PART_SWITCH
 }
 
-// Filters of 3074..4096 taps: h = (h_a, h_b) with 2048 taps in h_a.  Launch 1: y = h_a * x (writes the history);
-// launch 2: y += h_b * x(n - 2048).  Both are the 32-row (2049-tap) kernel at full rate; a decimation other than 1
-// (4 included) goes through the selecting store.  The history holds 4096 samples: 2048 of delay + the overlap.
 hipError_t launch_fft_two_partitions(const LaunchArgs &a)
 {
     if (a.chan || !a.fft_tables_b || a.hist_len < 2 * FFT_PART)
         return hipErrorInvalidConfiguration;
     LaunchArgs p = a;
-    p.T = FFT_PART;
-    const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
-    hipError_t e;
-    if (a.D == 1)
-        switch (key)
-        {
-        case 0: e = launch_fft_t<32, false, false, false>(p); break;
-        case 1: e = launch_fft_t<32, false, false, true>(p); break;
-        case 2: e = launch_fft_t<32, false, true, false>(p); break;
-        default: e = launch_fft_t<32, false, true, true>(p); break;
-        }
-    else
-        switch (key)
-        {
-        case 0: e = launch_fft_t<32, false, false, false, false, true>(p); break;
-        case 1: e = launch_fft_t<32, false, false, true, false, true>(p); break;
-        case 2: e = launch_fft_t<32, false, true, false, false, true>(p); break;
-        default: e = launch_fft_t<32, false, true, true, false, true>(p); break;
-        }
+    const hipError_t e = launch_fft_partition<false>(p);
     if (e != hipSuccess)
         return e;
-    p.T = a.T - FFT_PART;
     p.fft_tables = a.fft_tables_b;
     p.in_shift = FFT_PART;
     p.hist_out = nullptr; // the first launch wrote the next history
-    return launch_fft_acc(p);
+    return launch_fft_partition<true>(p);
 }
 #endif // 32-row unit
 #endif // IF_FIR_FFT_ROWS

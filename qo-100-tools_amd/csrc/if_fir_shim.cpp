@@ -166,22 +166,21 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
     }
     // NCO row phasors: per kept output for the decimate-by-4 kernel, per full-rate output for all others
     // int16 input: the kernel leaves the samples unscaled and the table carries the format's 2^-15
+    // decimation 4 and its multiples (8, 12, ..., 64: the same tail keeping every sub-th output) take the merged table and
+    // NCO row steps of decimation 4; decimation 2 (and 6, 10, ...) and the selecting-store route the plain one
+    const int F = tail_factor(ctx);
+    const int tabD = F == 4 ? 4 : 1;
+    const uint32_t tab_nco = 0u - ctx->nco_word * (F == 4 ? 4u : 1u);
     if (two)
     {
-        // full-rate tables (the decimation, 4 included, is a selecting store on this path)
+        // two partitions: each a filter of <= 2048 taps with its own table image
         const int step = eff_ctaps(ctx) ? 2 : 1, part = 2048;
-        if_fir::fft_build_tables(eff_taps(ctx), part, eff_ctaps(ctx), 1, 0u - ctx->nco_word, ctx->in_i16 ? 0x1p-15 : 1.0, tab);
-        if_fir::fft_build_tables(eff_taps(ctx) + (size_t)step * part, ctx->T - part, eff_ctaps(ctx), 1, 0u - ctx->nco_word,
+        if_fir::fft_build_tables(eff_taps(ctx), part, eff_ctaps(ctx), tabD, tab_nco, ctx->in_i16 ? 0x1p-15 : 1.0, tab);
+        if_fir::fft_build_tables(eff_taps(ctx) + (size_t)step * part, ctx->T - part, eff_ctaps(ctx), tabD, tab_nco,
                                  ctx->in_i16 ? 0x1p-15 : 1.0, tab + if_fir::FFT_TABLE_FLOATS);
     }
     else
-    {
-        // decimation 4 and its multiples (8, 12, ..., 64: the same tail keeping every sub-th output) take the merged table and
-        // NCO row steps of decimation 4; decimation 2 and the selecting-store route the plain one
-        const int F = tail_factor(ctx);
-        if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), F == 4 ? 4 : 1, 0u - ctx->nco_word * (F == 4 ? 4u : 1u),
-                                 ctx->in_i16 ? 0x1p-15 : 1.0, tab);
-    }
+        if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), tabD, tab_nco, ctx->in_i16 ? 0x1p-15 : 1.0, tab);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * tab_floats);

@@ -917,7 +917,8 @@ def test_contexts_on_concurrent_threads(fir, oracle):
 @pytest.mark.parametrize("t,d", [(255, 2), (255, 3), (1023, 8), (63, 5), (257, 16), (1025, 64), (255, 7), (255, 8), (2047, 16),
                                  (3073, 8), (1023, 2), (2047, 2), (3073, 2), (31, 2), (255, 32), (1023, 32), (127, 64), (3073, 64),
                                  (255, 12), (1023, 20), (255, 24), (513, 28), (2047, 40), (255, 48), (3073, 56), (255, 60), (127, 44),
-                                 (3073, 12), (255, 6), (3075, 12), (1023, 10), (255, 62), (513, 14), (3073, 30), (3075, 6)])
+                                 (3073, 12), (255, 6), (3075, 12), (1023, 10), (255, 62), (513, 14), (3073, 30), (3075, 6),
+                                 (4095, 2), (4095, 16), (3333, 4), (4001, 20)])
 def test_fft_backend_any_decimation(fir, oracle, t, d):
     """Decimations other than 1 and 4 on the overlap-save backend: the full-rate kernel keeps every D-th output (one
     64-bit division per block and lane, an exact multiply-shift per row); decimation 2 (frequency-domain fold + 2048-point
@@ -1064,11 +1065,12 @@ def test_fft_backend_long_filters(fir, oracle, t, d):
 
 
 @pytest.mark.parametrize("t,d", [(3075, 1), (3075, 4), (3075, 8), (4095, 1), (4095, 4), (4095, 8), (4096, 1), (4096, 4),
-                                 (4096, 8), (3074, 3)])
+                                 (4096, 8), (3074, 3), (4095, 2), (4096, 6), (3075, 12), (4095, 64), (3500, 10)])
 def test_fft_backend_two_partitions(fir, oracle, t, d):
     """3074..4096 taps on the overlap-save backend: h = (h_a, h_b) with 2048 taps in h_a; one launch
     computes h_a * x, a second one adds h_b * x(n - 2048) (the same 32-row kernel reading the input 2048 samples late,
-    accumulating store).  Against the float64 oracle: one call, ragged pieces shorter and longer than the delay, a
+    accumulating store; even decimations behind the decimating tails since round 3, the second partition adding to the
+    decimated outputs of the first).  Against the float64 oracle: one call, ragged pieces shorter and longer than the delay, a
     small grid, int16 input, complex taps, the NCO; and against the tap-split kernel."""
     rng = np.random.default_rng(t + d)
     def design(lo, hi):                                  # the designer makes odd lengths: an even one gets a small last tap
