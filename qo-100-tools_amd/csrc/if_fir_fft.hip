@@ -766,14 +766,14 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             constexpr int MU0_FIRST = OVL_ROWS / 4;
             constexpr int EARLY_B = I16 ? 3 : 1; // batches whose next-block rows are requested ahead of their inverse (no scratch)
             const int cs = lane & 3, mu1 = lane >> 2;
-            // NCO (a tuned single channel through the one-channel route, or a common fine offset of the whole slot grid):
+            // NCO (the context's NCO = a common fine offset of the whole slot grid):
             // output m = obase + 16 (mu0 - first) + mu1 is rotated by phasor(phi0 + delta m) = A(lane) * B(mu0 - first), B from
             // the table (step 16 delta, fft_build_tables)
             // with A(lane) = [phasor(phi0 + delta obase), wave-uniform, in SGPRs] * [phasor(delta mu1), table entries 32..47]
 #pragma unroll
             for (int b = 0; b < 4; b++)
             {
-                // a batch none of whose four slots is wanted (e.g. the single-channel decimate-by-16 route: slot 0 only) is
+                // a batch none of whose four slots is wanted is
                 // not inverted; its registers are refilled with next-block rows all the same
                 const bool wanted = ((chan.mask16 >> (4 * b)) & 15u) != 0u;
                 cf a[16];
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                     for (int ch = 0; ch < 2; ch++)
                     {
-                        if (ch == 1 && cp + 1 >= nch) // odd count (or the single-channel decimate-by-8 route): an empty second half
+                        if (ch == 1 && cp + 1 >= nch) // odd count: an empty second half
                         {
                             a[4 * i + 2] = (cf){0.f, 0.f};
                             a[4 * i + 3] = (cf){0.f, 0.f};

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical: the one-channel filter-bank route for decimation 8 / 16 / 32 / 64 compared here was removed later in round 3 --
+# every multiple of 4 now runs behind the decimate-by-4 tail; kept as the record of how the profiles/ file was produced)
 # r03_exp11.sh <tag> — GPU tests with decimation 32 / 64 through the decimate-by-16 tail; route on / off (3000) timing
 cd "$(dirname "$0")/.."
 O=gpurun_out/$1

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical: the one-channel filter-bank route for decimation 8 / 16 / 32 / 64 compared here was removed later in round 3 --
+# every multiple of 4 now runs behind the decimate-by-4 tail; kept as the record of how the profiles/ file was produced)
 # r03_exp14.sh <tag> — multiples of 8 / 16 through the decimate-by-4 tail keeping every 2nd, 4th, ... output (IF_FIR_EXP_TAIL4=1)
 # against the one-channel filter-bank route they take now
 cd "$(dirname "$0")/.."
