@@ -261,6 +261,9 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 #define IF_FIR_FFT_EARLY_GROUPS 3
 #endif
 // the first block's rows are requested ahead of the table copy (head of the launch)
+#ifndef IF_FIR_FFT_TABLE_COPY_UNROLLED
+#define IF_FIR_FFT_TABLE_COPY_UNROLLED 1 // table copy global -> LDS with all loads of a thread in flight (0: one at a time)
+#endif
 #ifndef IF_FIR_FFT_LOADS_FIRST
 #define IF_FIR_FFT_LOADS_FIRST 1
 #endif
@@ -527,8 +530,23 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     {
         const f4v_t *src = reinterpret_cast<const f4v_t *>(tables);
         f4v_t *dst = reinterpret_cast<f4v_t *>(smem);
+#if IF_FIR_FFT_TABLE_COPY_UNROLLED
+        // all 11 loads of a thread in flight before the first LDS write: as a plain loop the compiler waits for each load
+        // before the next one (11 memory round trips, ~8 us at the head of every launch with nothing else running on the CU)
+        constexpr int NV = LDS_XB / 16, NK = (NV + 511) / 512;
+        f4v_t tv[NK];
+#pragma unroll
+        for (int k = 0; k < NK; k++)
+            if ((int)threadIdx.x + 512 * k < NV)
+                tv[k] = src[threadIdx.x + 512 * k];
+#pragma unroll
+        for (int k = 0; k < NK; k++)
+            if ((int)threadIdx.x + 512 * k < NV)
+                dst[threadIdx.x + 512 * k] = tv[k];
+#else
         for (int i = threadIdx.x; i < LDS_XB / 16; i += 512)
             dst[i] = src[i];
+#endif
         if constexpr (CHAN == 16)
         {
             if (threadIdx.x < 16)
