@@ -194,6 +194,27 @@ int main(void)
         CHECK(if_fir_dev_free(pFir, pDevIn), "free");
     }
     if_fir_destroy(pFir);
+    pFir = NULL;
+
+    /* 7. decimations that run behind a tail keeping every sub-th output (12 = 4 x 3, 6 = 2 x 3), in two ragged pieces */
+    {
+        static const uint32_t aulDecim[2] = {12, 6};
+        for(uint32_t k = 0; k < 2; k++)
+        {
+            const uint32_t ulD = aulDecim[k];
+            const uint64_t ullCut = 33333, ullExpect = (SAMPLES + ulD - 1) / ulD;
+            uint64_t ullOutA = 0, ullOutB = 0;
+
+            CHECK(if_fir_init(&pFir, pfTaps, TAPS, ulD, SAMPLES, 0), "init (decimation %u): %s", ulD, if_fir_last_error(NULL));
+            CHECK(if_fir_process(pFir, pfX, pfY, ullCut, &ullOutA), "decimation %u, piece 1: %s", ulD, if_fir_last_error(pFir));
+            CHECK(if_fir_process(pFir, pfX + 2 * ullCut, pfY + 2 * ullOutA, SAMPLES - ullCut, &ullOutB) && ullOutA + ullOutB == ullExpect,
+                  "decimation %u, piece 2: %s", ulD, if_fir_last_error(pFir));
+            reference(pfTaps, TAPS, ulD, 0, pfX, SAMPLES, pdRef);
+            CHECK(max_rel_err(pfY, pdRef, 2 * ullExpect) <= 1e-6, "decimation %u error %g", ulD, max_rel_err(pfY, pdRef, 2 * ullExpect));
+            if_fir_destroy(pFir);
+            pFir = NULL;
+        }
+    }
     printf("if_fir_selftest: all checks passed\n");
     return 0;
 }
