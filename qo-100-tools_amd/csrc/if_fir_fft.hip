@@ -323,20 +323,20 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
 // shifts it by the call's decimation phase), so tail output number i (counted over the whole call) is kept when i is a
 // multiple of sub, as output i / sub.  The block's share (obase) is divided once per block, wave-uniform, in SGPRs; each
 // output then costs a multiply-shift (ceil(2^18 / sub), exact for numerators below 2^12: remainder + lane offset + step
-// < 1100).  sub = 1 keeps everything.
+// < 2100; checked over the whole range by tests/test_host.py).  sub = 1 keeps everything.
 struct KeepEvery
 {
     int64_t qU;     // floor(obase / sub), wave-uniform
     unsigned rem;   // obase mod sub, wave-uniform
     unsigned magic; // ceil(2^18 / sub)
     unsigned sub;
-    // obase = blk * lout (blk < 2^31, lout <= 960): divided in 32-bit pieces, blk = bq sub + br ->
+    // obase = blk * lout (blk < 2^31, lout <= 1920; 1, 2, 4, 8, 16: a shift): divided in 32-bit pieces, blk = bq sub + br ->
     // obase / sub = bq lout + (br lout) / sub -- a 64-bit division here costs a dozen temporaries the tails do not have
     __device__ __forceinline__ void init(int64_t blk, unsigned lout, unsigned sub_)
     {
         sub = sub_ ? sub_ : 1u;
         uint64_t q;
-        if ((sub & (sub - 1u)) == 0u) // 1, 2, 4: a shift
+        if ((sub & (sub - 1u)) == 0u) // a power of two: a shift
         {
             const uint64_t ob = (uint64_t)blk * lout;
             rem = (unsigned)ob & (sub - 1u);
