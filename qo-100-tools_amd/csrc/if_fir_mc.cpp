@@ -104,6 +104,11 @@ constexpr uint64_t MC_CHUNK_DEFAULT = 78 * MC_CHUNK_UNIT; // 16 773 120 samples,
 struct if_fir_mc_ctx
 {
     uint32_t channels = 0, taps = 0, decim = 0, rank = 0, world = 1;
+    // LOOPBACK (development library, IF_FIR_MC_LOOPBACK=1, one rank): this process plays BOTH ranks of a two-rank world over a
+    // one-rank communicator -- every send of the plan is matched by its receive in the same group, peer = itself -- so that
+    // the whole protocol (chunks, groups, events, staging slots, status word, the polling wait) runs over the real librccl on
+    // a one-GPU box.  Channels with an odd index are the "other rank's": staged, filtered from their slots, gathered back.
+    bool loop = false;
     uint32_t in_bytes = 8; // bytes per input sample (8 = float32 I,Q; 4 = int16 I,Q)
     uint64_t max_samples = 0;
     uint64_t consumed = 0;      // samples per channel since init/reset (every rank counts: sizes of the gather pieces)
@@ -219,7 +224,7 @@ static void mc_free(if_fir_mc_ctx *ctx)
 // demand (a longer chunk setting), never shrinks
 static uint8_t mc_ensure_staging(if_fir_mc_ctx *ctx, uint64_t need)
 {
-    if (ctx->rank == 0 || need <= ctx->slot_samples)
+    if ((ctx->rank == 0 && !ctx->loop) || need <= ctx->slot_samples)
         return 1;
     if (hipSetDevice(ctx->device) != hipSuccess)
         return 0;
@@ -231,7 +236,7 @@ static uint8_t mc_ensure_staging(if_fir_mc_ctx *ctx, uint64_t need)
     const size_t out_b = ((size_t)(need / ctx->decim + 2) * 8 + 255) & ~(size_t)255;
     for (uint32_t c = 0; c < ctx->channels; c++)
     {
-        if (!ctx->fir[c])
+        if (!ctx->fir[c] || (ctx->loop && (c & 1u) == 0u)) // (loopback: the even channels are rank 0's own, filtered in place)
             continue;
         if (ctx->stage_in[c])
             (void)hipFree(ctx->stage_in[c]);
@@ -295,15 +300,23 @@ IF_FIR_API uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, 
         mc_free(ctx);                 \
         return 0;                     \
     } while (0)
+#ifdef IF_FIR_DEVELOPMENT
+    {
+        const char *lb = getenv("IF_FIR_MC_LOOPBACK");
+        ctx->loop = ulWorld == 1 && ulChannels >= 2 && lb && *lb && *lb != '0';
+    }
+#endif
+    const bool transport = ulWorld > 1 || ctx->loop;
+    const uint32_t vworld = ctx->loop ? 2u : ulWorld; // ranks the transfer plan is made for
     hipError_t e = hipSetDevice(lDevice);
     if (e == hipSuccess)
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess && ulWorld > 1)
+    if (e == hipSuccess && transport)
         e = hipStreamCreateWithFlags(&ctx->xfer_stream, hipStreamNonBlocking);
-    if (e == hipSuccess && ulWorld > 1)
-        e = hipMalloc(reinterpret_cast<void **>(&ctx->d_status), (size_t)(1 + ulWorld) * 4);
-    if (e == hipSuccess && ulWorld > 1)
-        e = hipMemset(ctx->d_status, 0, (size_t)(1 + ulWorld) * 4);
+    if (e == hipSuccess && transport)
+        e = hipMalloc(reinterpret_cast<void **>(&ctx->d_status), (size_t)(1 + vworld) * 4);
+    if (e == hipSuccess && transport)
+        e = hipMemset(ctx->d_status, 0, (size_t)(1 + vworld) * 4);
     if (e != hipSuccess)
         MC_INIT_FAIL("if_fir_mc_init: device %d: %s", lDevice, hipGetErrorString(e));
     ctx->chunk_samples = MC_CHUNK_DEFAULT;
@@ -322,13 +335,20 @@ IF_FIR_API uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, 
         mc_free(ctx);
         return 0;
     }
-    if (ulWorld > 1)
+    if (transport)
     {
         ctx->api = rccl();
         if (!ctx->api)
             MC_INIT_FAIL("if_fir_mc_init: %s", g_rccl.why);
         ncclUniqueId id;
-        memcpy(id.internal, pubId, IF_FIR_MC_ID_BYTES);
+        if (ctx->loop)
+        {
+            const ncclResult_t ri = ctx->api->GetUniqueId(&id); // a one-rank communicator of its own
+            if (ri != ncclSuccess)
+                MC_INIT_FAIL("if_fir_mc_init: ncclGetUniqueId: %s", ctx->api->GetErrorString(ri));
+        }
+        else
+            memcpy(id.internal, pubId, IF_FIR_MC_ID_BYTES);
         const ncclResult_t r = ctx->api->CommInitRank(&ctx->comm, (int)ulWorld, id, (int)ulRank);
         if (r != ncclSuccess)
         {
@@ -413,6 +433,7 @@ struct McXfer
 {
     uint32_t kind, phase, group, peer, channel, chunk;
     uint64_t offset, bytes; // byte offset inside the channel's input (scatter) or output (gather) buffer
+    uint32_t as_rank = 0;   // the rank whose operation this is (loopback: one process posts both ranks' operations)
 };
 struct McChunk
 {
@@ -631,7 +652,37 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
     auto stage_in_at = [&](uint32_t c, uint32_t k) { return (char *)ctx->stage_in[c] + (size_t)(k & 1u) * ctx->slot_in_bytes; };
     auto stage_out_at = [&](uint32_t c, uint32_t k) { return (char *)ctx->stage_out[c] + (size_t)(k & 1u) * ctx->slot_out_bytes; };
     std::vector<McXfer> ops;
-    mc_plan(ctx->world, ctx->channels, ctx->rank, chunks, ctx->in_bytes, ops);
+    if (!ctx->loop)
+    {
+        mc_plan(ctx->world, ctx->channels, ctx->rank, chunks, ctx->in_bytes, ops);
+        for (McXfer &o : ops)
+            o.as_rank = ctx->rank;
+    }
+    else
+    {
+        // loopback: both ranks' operations of a two-rank world, group by group (rank 0's send and rank 1's receive of a
+        // transfer land in the same group), every peer = this one rank
+        std::vector<McXfer> r0, r1;
+        mc_plan(2, ctx->channels, 0, chunks, ctx->in_bytes, r0);
+        mc_plan(2, ctx->channels, 1, chunks, ctx->in_bytes, r1);
+        for (McXfer &o : r1)
+            o.as_rank = 1;
+        size_t i0 = 0, i1 = 0;
+        while (i0 < r0.size() || i1 < r1.size())
+        {
+            const uint32_t g = (i0 < r0.size() && (i1 >= r1.size() || r0[i0].group <= r1[i1].group)) ? r0[i0].group : r1[i1].group;
+            for (; i0 < r0.size() && r0[i0].group == g; i0++)
+                ops.push_back(r0[i0]);
+            for (; i1 < r1.size() && r1[i1].group == g; i1++)
+                ops.push_back(r1[i1]);
+        }
+        for (McXfer &o : ops)
+            o.peer = 0;
+    }
+    // a channel whose data goes through this process's staging slots: every owned channel of a rank other than 0
+    // (loopback: the odd channels, "rank 1's")
+    auto staged = [&](uint32_t c) { return ctx->loop ? (c & 1u) != 0u : !root; };
+    const bool has_staged = ctx->loop || !root;
     const uint32_t nchunks = (uint32_t)chunks.size();
     // events: chunk k's input has landed (transfer stream -> filter stream), chunk k is filtered (filter -> transfer)
     std::vector<hipEvent_t> ev_in(nchunks, nullptr), ev_out(nchunks, nullptr);
@@ -661,9 +712,9 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
             if (o.phase == MC_PHASE_STATUS)
                 buf = reinterpret_cast<char *>(ctx->d_status) + o.offset;
             else if (o.phase == MC_PHASE_SCATTER)
-                buf = root ? (char *)const_cast<void *>(ppDevIn[o.channel]) + o.offset : stage_in_at(o.channel, o.chunk);
+                buf = o.as_rank == 0 ? (char *)const_cast<void *>(ppDevIn[o.channel]) + o.offset : stage_in_at(o.channel, o.chunk);
             else
-                buf = root ? (char *)ppDevOut[o.channel] + o.offset : stage_out_at(o.channel, o.chunk);
+                buf = o.as_rank == 0 ? (char *)ppDevOut[o.channel] + o.offset : stage_out_at(o.channel, o.chunk);
             const ncclResult_t r = o.kind == MC_SEND
                                        ? ctx->api->Send(buf, o.bytes, ncclUint8, (int)o.peer, ctx->comm, ctx->xfer_stream)
                                        : ctx->api->Recv(buf, o.bytes, ncclUint8, (int)o.peer, ctx->comm, ctx->xfer_stream);
@@ -689,8 +740,8 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
             if (!ctx->fir[c])
                 continue;
             uint64_t m = 0;
-            const char *src = root ? (const char *)ppDevIn[c] + ch.in_first * ctx->in_bytes : stage_in_at(c, k);
-            char *dst = root ? (char *)ppDevOut[c] + ch.out_first * 8 : stage_out_at(c, k);
+            const char *src = !staged(c) ? (const char *)ppDevIn[c] + ch.in_first * ctx->in_bytes : stage_in_at(c, k);
+            char *dst = !staged(c) ? (char *)ppDevOut[c] + ch.out_first * 8 : stage_out_at(c, k);
             if (!if_fir_process_device(ctx->fir[c], src, dst, ch.in_count, &m))
             {
                 mc_err(ctx, "channel %u: %s", c, if_fir_last_error(ctx->fir[c]));
@@ -711,13 +762,13 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
         if (he == hipSuccess)                 \
             he = (call);                      \
     } while (0)
-    const bool moving = ctx->world > 1 && !ops.empty();
+    const bool moving = (ctx->world > 1 || ctx->loop) && !ops.empty();
     uint32_t group = 0;
     auto scatter_step = [&](uint32_t k) {
         if (moving)
         {
             post_group(group);
-            if (!root)
+            if (has_staged)
             {
                 MC_STEP(hipEventCreateWithFlags(&ev_in[k], hipEventDisableTiming));
                 MC_STEP(hipEventRecord(ev_in[k], ctx->xfer_stream));
@@ -727,7 +778,7 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
         group++;
         if (he == hipSuccess && !local_fail)
             filter_chunk(k);
-        if (moving && !root)
+        if (moving && has_staged)
         {
             MC_STEP(hipEventCreateWithFlags(&ev_out[k], hipEventDisableTiming));
             MC_STEP(hipEventRecord(ev_out[k], ctx->stream));
@@ -736,7 +787,7 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
     auto gather_step = [&](uint32_t k) {
         if (moving)
         {
-            if (!root && ev_out[k])
+            if (has_staged && ev_out[k])
                 MC_STEP(hipStreamWaitEvent(ctx->xfer_stream, ev_out[k], 0)); // send chunk k's outputs once they exist
             post_group(group);
         }
@@ -755,7 +806,7 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
         {
             // status word: the protocol above is completed even after a local failure, so that no peer is left waiting;
             // the root learns about it here
-            if (!root)
+            if (has_staged)
                 MC_STEP(hipMemsetD32Async((hipDeviceptr_t)ctx->d_status, local_fail ? 1 : 0, 1, ctx->xfer_stream));
             post_group(group);
         }
@@ -831,9 +882,10 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
         return 0;
     if (root && moving)
     {
-        std::vector<uint32_t> st(1 + ctx->world, 0);
+        const uint32_t vworld = ctx->loop ? 2u : ctx->world;
+        std::vector<uint32_t> st(1 + vworld, 0);
         MC_HIP(ctx, hipMemcpy(st.data(), ctx->d_status, st.size() * 4, hipMemcpyDeviceToHost));
-        for (uint32_t r = 1; r < ctx->world && r < ctx->channels; r++)
+        for (uint32_t r = 1; r < vworld && r < ctx->channels; r++)
             if (st[1 + r])
             {
                 mc_err(ctx, "if_fir_mc_process_device: rank %u reported a filter failure (its outputs are invalid)", r);

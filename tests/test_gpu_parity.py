@@ -554,6 +554,52 @@ def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
         assert l2 <= TOL and mx <= TOL, (t, d, l2, mx)
 
 
+def test_multi_channel_front_loopback_over_the_real_rccl(fir, oracle, torch_cuda):
+    """The multi-channel front's whole transfer protocol over the REAL librccl on one GPU (round 3): with IF_FIR_MC_LOOPBACK=1 the
+    development library lets one process play both ranks of a two-rank world over a one-rank communicator -- every send of
+    the plan is matched by its receive in the same group, peer = itself.  Chunks, grouped transfers, the two staging slots,
+    events between the transfer and filter streams, the status word and the polling wait all run as between GPUs; only the
+    wire is missing.  Results: bit-identical to the same calls without any transport, at decimation phases != 0 too."""
+    torch = torch_cuda
+    t, d, nch = 255, 4, 4
+    cuts = [0, 600_001, 1_300_009]
+    n = cuts[-1]
+    taps = np.stack([fir.bpf_design(t, 0.02 + 0.05 * c, 0.08 + 0.05 * c) for c in range(nch)])
+    dev_in = [torch.from_numpy(oracle.synth_iq(n, 60 + c)).cuda() for c in range(nch)]
+
+    def run(loopback):
+        if loopback:
+            os.environ["IF_FIR_MC_LOOPBACK"] = "1"
+        try:
+            mc = fir.IfFirMc(taps, d, n, dev=True)
+        except fir.IfFirError as e:
+            if loopback and "librccl" in str(e):
+                pytest.skip("librccl cannot be opened here: %s" % e)
+            raise
+        finally:
+            os.environ.pop("IF_FIR_MC_LOOPBACK", None)
+        with mc:
+            mc.set_chunk_samples(fir.MC_CHUNK_UNIT)      # 215 040-sample chunks: 3 + 4 chunks in the two calls
+            parts = [[] for _ in range(nch)]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                m_exp = oracle.out_count(a, b - a, d)
+                outs = [torch.full((2 * m_exp + 8,), 7.0, dtype=torch.float32, device="cuda") for _ in range(nch)]
+                pieces = [x[2 * a:2 * b].clone() for x in dev_in]
+                torch.cuda.synchronize()
+                assert mc.process_device([p.data_ptr() for p in pieces], [o.data_ptr() for o in outs], b - a) == m_exp
+                for c in range(nch):
+                    o = outs[c].cpu().numpy()
+                    assert np.all(o[2 * m_exp:] == 7.0)
+                    parts[c].append(o[:2 * m_exp])
+            return [np.concatenate(p) for p in parts]
+    plain = run(False)
+    looped = run(True)
+    for c in range(nch):
+        assert np.array_equal(plain[c], looped[c]), c
+    l2, mx = oracle.err_metrics(looped[1], oracle.fir_f64(taps[1], dev_in[1].cpu().numpy(), d))
+    assert l2 <= TOL and mx <= TOL, (l2, mx)
+
+
 def test_overlap_save_backend_takes_sample_aligned_pointers(fir, oracle, torch_cuda):
     """The overlap-save kernel moves one sample per lane: input and output pointers need only be aligned to a sample (8
     bytes; 4 for int16 input), which the chunked multi-channel front relies on; the results are those of aligned buffers."""

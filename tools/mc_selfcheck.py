@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""mc_selfcheck.py — exercises if_fir_mc_* across ranks on a multi-GPU node (not runnable on the one-GPU box).
+"""mc_selfcheck.py — exercises if_fir_mc_* across ranks on a multi-GPU node (on a one-GPU box: IF_FIR_MC_LOOPBACK=1 python
+tools/mc_selfcheck.py runs the same protocol over the real librccl with both ranks played by one process).
 
 launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         tools/mc_selfcheck.py [channels] [log2 samples]
@@ -50,8 +51,11 @@ def main():
             uid = bytes(idt.cpu().numpy().tobytes())
     d, t = 4, 255
     taps = np.stack([fir.bpf_design(t, 0.02 + 0.05 * c, 0.06 + 0.05 * c) for c in range(channels)])
+    # IF_FIR_MC_LOOPBACK=1 with one rank (development library): this process plays both ranks of a two-rank world over a
+    # one-rank communicator of the real librccl -- the protocol end to end on a one-GPU box, only the wire missing
+    loopback = world == 1 and os.environ.get("IF_FIR_MC_LOOPBACK", "0") not in ("", "0")
     try:
-        mc_ctx = fir.IfFirMc(taps, d, n, device=local, rank=rank, world=world, unique_id=uid)
+        mc_ctx = fir.IfFirMc(taps, d, n, device=local, rank=rank, world=world, unique_id=uid, dev=loopback)
     except fir.IfFirError as e:
         print("rank %d: if_fir_mc_init failed: %s" % (rank, e), flush=True)
         sys.exit(2)
@@ -87,8 +91,9 @@ def main():
                     if not same:
                         print("call %d channel %d (rank %d): MISMATCH max |diff| %g" %
                               (call, c, fir.mc_owner(c, world), (ref - outs[c]).abs().max().item()))
-                print("call %d: %d channels x 2^%d samples over %d ranks: %.2f ms (%.1f GS/s end to end) %s" %
-                      (call, channels, int(np.log2(n)), world, dt * 1e3, channels * n / dt / 1e9, "OK" if ok else "FAIL"))
+                print("call %d: %d channels x 2^%d samples over %d ranks%s: %.2f ms (%.1f GS/s end to end) %s" %
+                      (call, channels, int(np.log2(n)), world, " (LOOPBACK: two virtual ranks, real librccl)" if loopback else "",
+                       dt * 1e3, channels * n / dt / 1e9, "OK" if ok else "FAIL"))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
