@@ -192,7 +192,7 @@ uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ulFormat);
  * context refuses further calls (destroy it and create a new one); the peers notice through the communicator's
  * asynchronous error state, which their waits poll, or at the latest after IF_FIR_MC_TIMEOUT_S seconds (best effort:
  * the failure paths have run against a stand-in transport only; the protocol itself also over the real librccl in
- * loopback, one process playing both ranks -- no multi-GPU node was available to the build). */
+ * loopback, one process playing all ranks -- no multi-GPU node was available to the build). */
 uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDevIn, void *const *ppDevOut,
                                  uint64_t ullSamples, uint64_t *pullOutSamples);
 /* chunk length of the following calls: 0 = default (16 773 120 samples), UINT64_MAX = never split, otherwise a multiple of

@@ -17,9 +17,10 @@
  *                  tolerance; A/B timing)
  *   4000           the next call fails before anything is launched (IF_FIR_DEBUG=1): lets tests reach callers' error paths
  * Environment (dev library only): IF_FIR_DEBUG=1 IF_FIR_VARIANT=n preselects a variant at if_fir_init.
- * IF_FIR_MC_LOOPBACK=1 (dev library only, read by if_fir_mc_init with one rank and >= 2 channels): this process plays both ranks
- * of a two-rank world over a one-rank communicator of the real librccl (every send matched by its receive in the same
- * group, peer = itself): the multi-channel front's whole transfer protocol on a one-GPU box (tools/mc_selfcheck.py).
+ * IF_FIR_MC_LOOPBACK=N (dev library only, read by if_fir_mc_init with one rank and >= 2 channels; N = 2..16 virtual ranks, 1 = 2):
+ * this process plays all ranks of an N-rank world over a one-rank communicator of the real librccl (every send matched by its
+ * receive in the same group, peer = itself): the multi-channel front's whole transfer protocol on a one-GPU box
+ * (tools/mc_selfcheck.py).
  */
 #ifndef IF_FIR_DEBUG_H
 #define IF_FIR_DEBUG_H

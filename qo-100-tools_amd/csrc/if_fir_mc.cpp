@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -104,11 +105,12 @@ constexpr uint64_t MC_CHUNK_DEFAULT = 78 * MC_CHUNK_UNIT; // 16 773 120 samples,
 struct if_fir_mc_ctx
 {
     uint32_t channels = 0, taps = 0, decim = 0, rank = 0, world = 1;
-    // LOOPBACK (development library, IF_FIR_MC_LOOPBACK=1, one rank): this process plays BOTH ranks of a two-rank world over a
-    // one-rank communicator -- every send of the plan is matched by its receive in the same group, peer = itself -- so that
-    // the whole protocol (chunks, groups, events, staging slots, status word, the polling wait) runs over the real librccl on
-    // a one-GPU box.  Channels with an odd index are the "other rank's": staged, filtered from their slots, gathered back.
+    // LOOPBACK (development library, IF_FIR_MC_LOOPBACK=N, one rank): this process plays ALL ranks of an N-rank world (2..16) over
+    // a one-rank communicator -- every send of the plan is matched by its receive in the same group, peer = itself -- so that
+    // the whole protocol (chunks, groups, events, staging slots, status words, the polling wait) runs over the real librccl on
+    // a one-GPU box.  Channel c is "rank c mod N's": all but rank 0's are staged, filtered from their slots, gathered back.
     bool loop = false;
+    uint32_t vranks = 0;
     uint32_t in_bytes = 8; // bytes per input sample (8 = float32 I,Q; 4 = int16 I,Q)
     uint64_t max_samples = 0;
     uint64_t consumed = 0;      // samples per channel since init/reset (every rank counts: sizes of the gather pieces)
@@ -236,7 +238,7 @@ static uint8_t mc_ensure_staging(if_fir_mc_ctx *ctx, uint64_t need)
     const size_t out_b = ((size_t)(need / ctx->decim + 2) * 8 + 255) & ~(size_t)255;
     for (uint32_t c = 0; c < ctx->channels; c++)
     {
-        if (!ctx->fir[c] || (ctx->loop && (c & 1u) == 0u)) // (loopback: the even channels are rank 0's own, filtered in place)
+        if (!ctx->fir[c] || (ctx->loop && c % ctx->vranks == 0u)) // (loopback: virtual rank 0's own channels are filtered in place)
             continue;
         if (ctx->stage_in[c])
             (void)hipFree(ctx->stage_in[c]);
@@ -303,11 +305,13 @@ IF_FIR_API uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, 
 #ifdef IF_FIR_DEVELOPMENT
     {
         const char *lb = getenv("IF_FIR_MC_LOOPBACK");
-        ctx->loop = ulWorld == 1 && ulChannels >= 2 && lb && *lb && *lb != '0';
+        const int nv = lb ? atoi(lb) : 0;
+        ctx->vranks = nv == 1 ? 2u : (nv >= 2 && nv <= 16) ? (uint32_t)nv : 0u; // "1" = two virtual ranks
+        ctx->loop = ulWorld == 1 && ulChannels >= 2 && ctx->vranks >= 2;
     }
 #endif
     const bool transport = ulWorld > 1 || ctx->loop;
-    const uint32_t vworld = ctx->loop ? 2u : ulWorld; // ranks the transfer plan is made for
+    const uint32_t vworld = ctx->loop ? ctx->vranks : ulWorld; // ranks the transfer plan is made for
     hipError_t e = hipSetDevice(lDevice);
     if (e == hipSuccess)
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -660,28 +664,35 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
     }
     else
     {
-        // loopback: both ranks' operations of a two-rank world, group by group (rank 0's send and rank 1's receive of a
+        // loopback: every rank's operations of the virtual world, group by group (rank 0's send and the owner's receive of a
         // transfer land in the same group), every peer = this one rank
-        std::vector<McXfer> r0, r1;
-        mc_plan(2, ctx->channels, 0, chunks, ctx->in_bytes, r0);
-        mc_plan(2, ctx->channels, 1, chunks, ctx->in_bytes, r1);
-        for (McXfer &o : r1)
-            o.as_rank = 1;
-        size_t i0 = 0, i1 = 0;
-        while (i0 < r0.size() || i1 < r1.size())
+        // RCCL matches the sends and receives between one pair of peers in the order they are posted, and here every
+        // operation has the same pair (self, self): within a group the operations are put into transfer order -- channel
+        // by channel (status words: owner by owner) -- so that the k-th send meets the k-th receive
+        for (uint32_t r = 0; r < ctx->vranks; r++)
         {
-            const uint32_t g = (i0 < r0.size() && (i1 >= r1.size() || r0[i0].group <= r1[i1].group)) ? r0[i0].group : r1[i1].group;
-            for (; i0 < r0.size() && r0[i0].group == g; i0++)
-                ops.push_back(r0[i0]);
-            for (; i1 < r1.size() && r1[i1].group == g; i1++)
-                ops.push_back(r1[i1]);
+            std::vector<McXfer> mine;
+            mc_plan(ctx->vranks, ctx->channels, r, chunks, ctx->in_bytes, mine);
+            for (McXfer &o : mine)
+            {
+                o.as_rank = r;
+                ops.push_back(o);
+            }
         }
+        auto remote = [](const McXfer &o) { return o.as_rank == 0 ? o.peer : o.as_rank; }; // the rank other than 0 of a transfer
+        std::stable_sort(ops.begin(), ops.end(), [&](const McXfer &a, const McXfer &b) {
+            if (a.group != b.group)
+                return a.group < b.group;
+            if (a.channel != b.channel)
+                return a.channel < b.channel;
+            return remote(a) < remote(b);
+        });
         for (McXfer &o : ops)
             o.peer = 0;
     }
     // a channel whose data goes through this process's staging slots: every owned channel of a rank other than 0
-    // (loopback: the odd channels, "rank 1's")
-    auto staged = [&](uint32_t c) { return ctx->loop ? (c & 1u) != 0u : !root; };
+    // (loopback: the channels of the virtual ranks other than 0)
+    auto staged = [&](uint32_t c) { return ctx->loop ? c % ctx->vranks != 0u : !root; };
     const bool has_staged = ctx->loop || !root;
     const uint32_t nchunks = (uint32_t)chunks.size();
     // events: chunk k's input has landed (transfer stream -> filter stream), chunk k is filtered (filter -> transfer)
@@ -882,7 +893,7 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
         return 0;
     if (root && moving)
     {
-        const uint32_t vworld = ctx->loop ? 2u : ctx->world;
+        const uint32_t vworld = ctx->loop ? ctx->vranks : ctx->world;
         std::vector<uint32_t> st(1 + vworld, 0);
         MC_HIP(ctx, hipMemcpy(st.data(), ctx->d_status, st.size() * 4, hipMemcpyDeviceToHost));
         for (uint32_t r = 1; r < vworld && r < ctx->channels; r++)

@@ -555,21 +555,21 @@ def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
 
 
 def test_multi_channel_front_loopback_over_the_real_rccl(fir, oracle, torch_cuda):
-    """The multi-channel front's whole transfer protocol over the REAL librccl on one GPU (round 3): with IF_FIR_MC_LOOPBACK=1 the
-    development library lets one process play both ranks of a two-rank world over a one-rank communicator -- every send of
+    """The multi-channel front's whole transfer protocol over the REAL librccl on one GPU (round 3): with IF_FIR_MC_LOOPBACK=N the
+    development library lets one process play all ranks of an N-rank world over a one-rank communicator -- every send of
     the plan is matched by its receive in the same group, peer = itself.  Chunks, grouped transfers, the two staging slots,
     events between the transfer and filter streams, the status word and the polling wait all run as between GPUs; only the
     wire is missing.  Results: bit-identical to the same calls without any transport, at decimation phases != 0 too."""
     torch = torch_cuda
-    t, d, nch = 255, 4, 4
-    cuts = [0, 600_001, 1_300_009]
+    t, d, nch = 255, 4, 7        # (7 channels over 3 virtual ranks: ranks with 3, 2 and 2 channels -- the order of a group's
+    cuts = [0, 600_001, 1_300_009]  #  sends and receives matters then: RCCL pairs them up in posting order)
     n = cuts[-1]
     taps = np.stack([fir.bpf_design(t, 0.02 + 0.05 * c, 0.08 + 0.05 * c) for c in range(nch)])
     dev_in = [torch.from_numpy(oracle.synth_iq(n, 60 + c)).cuda() for c in range(nch)]
 
     def run(loopback):
         if loopback:
-            os.environ["IF_FIR_MC_LOOPBACK"] = "1"
+            os.environ["IF_FIR_MC_LOOPBACK"] = str(loopback)     # the number of virtual ranks
         try:
             mc = fir.IfFirMc(taps, d, n, dev=True)
         except fir.IfFirError as e:
@@ -592,10 +592,11 @@ def test_multi_channel_front_loopback_over_the_real_rccl(fir, oracle, torch_cuda
                     assert np.all(o[2 * m_exp:] == 7.0)
                     parts[c].append(o[:2 * m_exp])
             return [np.concatenate(p) for p in parts]
-    plain = run(False)
-    looped = run(True)
-    for c in range(nch):
-        assert np.array_equal(plain[c], looped[c]), c
+    plain = run(0)
+    for vranks in (2, 3, 4):
+        looped = run(vranks)
+        for c in range(nch):
+            assert np.array_equal(plain[c], looped[c]), (vranks, c)
     l2, mx = oracle.err_metrics(looped[1], oracle.fir_f64(taps[1], dev_in[1].cpu().numpy(), d))
     assert l2 <= TOL and mx <= TOL, (l2, mx)
 

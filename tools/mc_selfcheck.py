@@ -51,7 +51,7 @@ def main():
             uid = bytes(idt.cpu().numpy().tobytes())
     d, t = 4, 255
     taps = np.stack([fir.bpf_design(t, 0.02 + 0.05 * c, 0.06 + 0.05 * c) for c in range(channels)])
-    # IF_FIR_MC_LOOPBACK=1 with one rank (development library): this process plays both ranks of a two-rank world over a
+    # IF_FIR_MC_LOOPBACK=N with one rank (development library): this process plays all ranks of an N-rank world over a
     # one-rank communicator of the real librccl -- the protocol end to end on a one-GPU box, only the wire missing
     loopback = world == 1 and os.environ.get("IF_FIR_MC_LOOPBACK", "0") not in ("", "0")
     try:
@@ -92,7 +92,7 @@ def main():
                         print("call %d channel %d (rank %d): MISMATCH max |diff| %g" %
                               (call, c, fir.mc_owner(c, world), (ref - outs[c]).abs().max().item()))
                 print("call %d: %d channels x 2^%d samples over %d ranks%s: %.2f ms (%.1f GS/s end to end) %s" %
-                      (call, channels, int(np.log2(n)), world, " (LOOPBACK: two virtual ranks, real librccl)" if loopback else "",
+                      (call, channels, int(np.log2(n)), world, " (LOOPBACK: %s virtual ranks, real librccl)" % os.environ["IF_FIR_MC_LOOPBACK"] if loopback else "",
                        dt * 1e3, channels * n / dt / 1e9, "OK" if ok else "FAIL"))
     if world > 1:
         dist.barrier()
