@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+BARRIER_COVER_STEPS = 40   # multi-rank runs: untimed passes of the step queued in front of the opening barrier (see main)
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak, packed FMA counted
 
 WORKLOADS = {
@@ -500,6 +501,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # the first collective of a process sets the transport up (6.5 ms on one MI355X, tools/barrier_probe.py; later ones
+        # take 30 us): spent here, not in front of the timed steps, where an idle device falls out of its settled power state
+        dist.barrier()
+        dist.barrier()
 
     pkg = graft.load_pkg()
     fir = pkg.if_fir
@@ -678,8 +683,13 @@ def main():
 
     for _ in range(args.warmup):
         step_stream()
-    torch.cuda.synchronize()
     if use_dist:
+        # the opening barrier's host round trip runs while the device is still busy with (untimed) passes of the step:
+        # an idle gap here costs the settled power state the conditioning created, and a multi-rank run would then time
+        # "cold" kernels where the one-rank run times settled ones (measured with IF_FIR_BENCH_DIST=1 on one GPU:
+        # 0.583 instead of 0.476 ms per step)
+        for _ in range(BARRIER_COVER_STEPS):
+            step_stream()
         dist.barrier()
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -849,8 +859,11 @@ def main():
                        "backend": names[f.get_backend()],
                        "device": f.device_info()},
             "conditioning": {"device_ms": round(conditioning_ms, 1), "extra_passes_of_the_step": cond_passes,
+                             "passes_covering_the_opening_barrier": BARRIER_COVER_STEPS if use_dist else 0,
                              "note": "untimed GPU work ahead of the W warm-up steps (comparison measurements + passes "
-                                     "of the same step) so that the timed steps run in the settled power state"},
+                                     "of the same step) so that the timed steps run in the settled power state; "
+                                     "multi-rank runs queue further untimed passes in front of the opening barrier so "
+                                     "that the device is not idle during its host round trip"},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_over_algorithmic": round(traffic / bytes_per_launch, 4) if traffic else None,
