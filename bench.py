@@ -871,9 +871,11 @@ def main():
                          "kernel_ms": round(dev_ms_max, 4),
                          "cold_kernel_ms": round(cold_ms_max, 4) if cold_ms is not None else None,
                          "cold_frac": round(bytes_per_launch / (cold_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if cold_ms is not None else None,
-                         "cold_note": "the same W warm-up + K steps timed BEFORE any conditioning (chip coming from idle: its "
-                                      "power management clamps the clock for the first ~20 launches); `value` and `frac` are "
-                                      "the settled rate of a filter in continuous service",
+                         "cold_note": "the same W warm-up + K steps timed BEFORE any conditioning, i.e. launches ~6-25 after idle: "
+                                      "the power controller's transient (launch by launch, profiles/r03_cold_transient.txt: "
+                                      "launches 2-3 after idle 0.44 ms, launches 5-10 0.67-0.72 ms, sustained 0.47-0.48 ms "
+                                      "again after ~35 ms); `value` and `frac` are the sustained rate of a filter in "
+                                      "continuous service",
                          "kernel_ms_median": round(float(np.median(per_step)), 4),
                          "kernel_ms_min": round(float(np.min(per_step)), 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
