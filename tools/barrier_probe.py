@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""barrier_probe.py — how long RCCL's barrier / all_reduce take through torch.distributed with one rank on this box (development
+tool): the first collective of a process sets the transport up (6.5 ms on MI355X), later ones take ~30 us.  bench.py spends the
+first ones right after init_process_group for that reason."""
 import os, time, torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29512")
 torch.cuda.set_device(0)
