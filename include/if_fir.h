@@ -195,7 +195,7 @@ uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ulFormat);
  * loopback, one process playing all ranks -- no multi-GPU node was available to the build). */
 uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDevIn, void *const *ppDevOut,
                                  uint64_t ullSamples, uint64_t *pullOutSamples);
-/* chunk length of the following calls: 0 = default (16 773 120 samples), UINT64_MAX = never split, otherwise a multiple of
+/* chunk length of the following calls: 0 = default (16 773 120 samples; with one rank: never split), UINT64_MAX = never split, otherwise a multiple of
  * 215 040 samples (the lcm of the overlap-save block advances).  The library rounds it up to a multiple of twice the
  * decimation and, where the kernel's block grid follows the decimation phase (every even decimation, <= 3073 taps), makes the first chunk of an
  * off-phase call that many samples longer: the blocks of a chunked call are then the blocks of an unchunked one and the

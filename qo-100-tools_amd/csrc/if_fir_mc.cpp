@@ -323,7 +323,9 @@ IF_FIR_API uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, 
         e = hipMemset(ctx->d_status, 0, (size_t)(1 + vworld) * 4);
     if (e != hipSuccess)
         MC_INIT_FAIL("if_fir_mc_init: device %d: %s", lDevice, hipGetErrorString(e));
-    ctx->chunk_samples = MC_CHUNK_DEFAULT;
+    // (one rank moves nothing: its calls are not split unless asked to -- a 2^24-sample piece keeps the overlap-save kernel's
+    // 2048 waves busy for two blocks each and runs at half the rate of a whole 2^28-sample call)
+    ctx->chunk_samples = transport ? MC_CHUNK_DEFAULT : 0;
     for (uint32_t c = 0; c < ulChannels; c++)
     {
         if (if_fir_mc_owner(c, ulWorld) != ulRank)
@@ -596,7 +598,7 @@ IF_FIR_API uint8_t if_fir_mc_set_chunk_samples(if_fir_mc_ctx_t *pCtx, uint64_t u
     if (ullChunk == UINT64_MAX)
         pCtx->chunk_samples = 0;
     else if (ullChunk == 0)
-        pCtx->chunk_samples = MC_CHUNK_DEFAULT;
+        pCtx->chunk_samples = (pCtx->world > 1 || pCtx->loop) ? MC_CHUNK_DEFAULT : 0;
     else if (ullChunk % MC_CHUNK_UNIT)
     {
         mc_err(pCtx, "if_fir_mc_set_chunk_samples: %llu is not a multiple of %llu samples", (unsigned long long)ullChunk,
