@@ -46,7 +46,7 @@ uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t 
 /* host-only: block-queue layout of an overlap-save launch: pllOut[6] = blocks per group, groups, static groups per
  * workgroup, 0, upper bound of the global ticket counter, workgroups */
 uint8_t if_fir_debug_fft_schedule(uint64_t ullBlocks, uint32_t ulWorkgroups, int64_t *pllOut);
-/* bounded waits of the overlap-save kernel's block queue that expired since if_fir_init (third word of the context's
+/* bounded waits of the overlap-save kernel's block queue that expired since if_fir_init (a word of the context's
  * queue block; 0 in a healthy run: a wave that gives up leaves its blocks unwritten instead of hanging the device) */
 uint8_t if_fir_debug_queue_faults(if_fir_ctx_t *pCtx, uint32_t *pulFaults);
 /* host-only: the transfer plan of one rank of the multi-channel front for one call, 8 uint64 per operation {kind 0 send /

@@ -172,7 +172,10 @@ static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 constexpr int LDS_Q = LDS_XB + FFT_WAVES * XBUF; // workgroup block queue: slot counter (16 B) + ring of group entries
 constexpr int LDS_QPTR = LDS_Q + 16 + Q_RING * 8; // 16-slot bank: the 16 output pointers (kept out of the SGPRs)
 constexpr int LDS_QNCO = LDS_QPTR + 16 * 8; // bank tails with an NCO: the block's rotation phasor, one 8-byte word per wave
-constexpr int FFT_LDS_BYTES = LDS_QNCO + FFT_WAVES * 8;
+// tail phase of the queue (short launches): tail word (8 B) and the four SIMDs' claim counters (4 x 4 B)
+constexpr int LDS_QTAIL = LDS_QNCO + FFT_WAVES * 8, LDS_QCLAIM = LDS_QTAIL + 16;
+constexpr int FFT_LDS_BYTES = LDS_QCLAIM + 16;
+static_assert(FFT_LDS_BYTES <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 
 __device__ __forceinline__ void exchange1_fwd(cf (&r)[64])
 {
@@ -363,13 +366,46 @@ struct KeepEvery
 };
 
 // ---- block queue (two levels): if_fir_fft_queue.h, shared with the host simulation --------------------------------------
-// LDS image: the current-group word at LDS_Q, the look-ahead ring at LDS_Q + 16.
+// Global queue block (32 bytes per context): words 0, 1 = group ticket counters (launches alternate; each launch zeroes the
+// other one for the launch behind it), words 2, 3 = tail ticket counters (likewise), word 4 = expired bounded waits.
 struct DevQueue
 {
     char *smem;
     unsigned int *gqueue; // this launch's global ticket counter
-    unsigned int *faultw; // third word of the queue block: bounded waits that expired (0 in a healthy launch)
+    unsigned int *tqueue; // this launch's tail ticket counter
+    unsigned int *faultw; // bounded waits that expired (0 in a healthy launch)
     int lane;
+    __device__ __forceinline__ unsigned long long *tailw() const { return reinterpret_cast<unsigned long long *>(smem + LDS_QTAIL); }
+    __device__ __forceinline__ unsigned tail_claim(unsigned simd)
+    {
+        unsigned c = 0;
+        if (lane == 0)
+            c = __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(smem + LDS_QCLAIM) + simd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(c);
+    }
+    __device__ __forceinline__ unsigned long long tail_add()
+    {
+        unsigned long long w = 0;
+        if (lane == 0)
+            w = __hip_atomic_fetch_add(tailw(), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return uniform(w);
+    }
+    __device__ __forceinline__ unsigned long long tail_load()
+    {
+        return uniform(__hip_atomic_load(tailw(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    __device__ __forceinline__ void tail_store(unsigned long long v)
+    {
+        if (lane == 0)
+            __hip_atomic_store(tailw(), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ unsigned tail_ticket()
+    {
+        unsigned t = 0;
+        if (lane == 0)
+            t = atomicAdd(tqueue, 1u);
+        return __builtin_amdgcn_readfirstlane(t);
+    }
     __device__ __forceinline__ unsigned long long *cur() const { return reinterpret_cast<unsigned long long *>(smem + LDS_Q); }
     __device__ __forceinline__ unsigned long long *ring() const { return reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16); }
     static __device__ __forceinline__ unsigned long long uniform(unsigned long long v)
@@ -476,7 +512,7 @@ template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, int CHAN, bool DECN, bool
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int HL, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
-                                                        unsigned int *queue, unsigned long long *dbg, int32_t diag,
+                                                        int64_t nblocks_main, unsigned int *queue, unsigned long long *dbg, int32_t diag,
                                                         uint32_t nco_phi0, uint32_t nco_delta, ChanArgs chan,
                                                         uint32_t qsel, void *__restrict__ hist_out,
                                                         int32_t decn, int32_t decn_n0, int64_t decn_m, int32_t in_shift)
@@ -555,16 +591,23 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         // block queue (if_fir_fft_queue.h): the current-group word and the look-ahead ring
         if (threadIdx.x < Q_RING)
             reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16)[threadIdx.x] = queue_ring_init(threadIdx.x, blockIdx.x, gridDim.x);
+        if (threadIdx.x < 4)
+            reinterpret_cast<unsigned int *>(smem + LDS_QCLAIM)[threadIdx.x] = 0u;
         if (threadIdx.x == 0)
         {
             *reinterpret_cast<unsigned long long *>(smem + LDS_Q) = queue_cur_init(blockIdx.x, gridDim.x, plain_start);
-            // the other global counter is the next launch's: zero it here (this launch never touches it)
+            *reinterpret_cast<unsigned long long *>(smem + LDS_QTAIL) = 0ull;
+            // the other global counters are the next launch's: zero them here (this launch never touches them)
             if (blockIdx.x == 0)
+            {
                 queue[qsel ^ 1u] = 0u;
+                queue[2u + (qsel ^ 1u)] = 0u;
+            }
         }
     }
     __syncthreads();
-    DevQueue dq{smem, queue + qsel, queue + 2, lane};
+    DevQueue dq{smem, queue + qsel, queue + 2 + qsel, queue + 4, lane};
+    const unsigned simd = (unsigned)wid & 3u; // waves w and w + 4 of a workgroup share a SIMD
     if (plain_start && wid == 0)
         queue_start(dq); // the fetch the (static) slot 0 of local group 0 owes
     // streaming state: the history of the NEXT call = the last HL samples of (history || input) (HL = the block overlap,
@@ -628,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // diag 64 (development, results stay correct): waves 4-7 of every workgroup leave at once = one wave per SIMD
     // (occupancy experiment; the queue hands their share to the others)
     if (!plain_start)
-        blk = (diag & 32) ? 0 : ((diag & 64) && wid >= FFT_WAVES / 2) ? nblocks : queue_take(dq, nblocks);
+        blk = (diag & 32) ? 0 : ((diag & 64) && wid >= FFT_WAVES / 2) ? nblocks : queue_take(dq, simd, nblocks_main, nblocks);
     // diag 32 (development, results stay correct): static wave-interleaved blocks, no queue: block = it * waves + wave
     const bool static_map = (diag & 32) != 0;
     const int act_waves = (diag & 64) ? FFT_WAVES / 2 : FFT_WAVES;
@@ -743,7 +786,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         {
             // taken here: the block's own rows have all landed and the next block's are not issued yet, so the wait
             // behind the (rare) global atomic inside drains nothing
-            blk_next = queue_take(dq, nblocks);
+            blk_next = queue_take(dq, simd, nblocks_main, nblocks);
         }
         const int64_t s0n = blk_next * L - OVL + n0 - in_shift;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
@@ -1445,6 +1488,9 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     FftSchedule sch;
     fft_schedule(nblocks, wgs_max, sch);
     const int64_t wgs = sch.wgs;
+    // groups and tail (if_fir_fft_queue.h): a remainder of at most one block per SIMD is kept out of the groups; diag 256
+    // (development) switches the tail off
+    const int64_t nblocks_main = (a.diag & 256) ? nblocks : queue_main_blocks(nblocks, wgs);
     // two global counters used alternately: a launch draws from one and zeroes the other for the launch behind it
     // (same stream, so it has finished before that one starts); after anybody else touched the words, start over
     uint32_t qsel = 0;
@@ -1452,7 +1498,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
         qsel = *a.queue_base & 1u;
     else
     {
-        hipError_t e = hipMemsetAsync(a.queue, 0, 8, a.stream);
+        hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);
         if (e != hipSuccess)
             return e;
     }
@@ -1464,7 +1510,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), FFT_LDS_BYTES, a.stream,
                        reinterpret_cast<const f2v *>(a.in), reinterpret_cast<f2v *>(a.out),
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist_full), a.hist_len, a.N,
-                       n0_rate, m_rate, nblocks, (unsigned int *)a.queue,
+                       n0_rate, m_rate, nblocks, nblocks_main, (unsigned int *)a.queue,
                        (unsigned long long *)a.dbg, (int32_t)a.diag,
                        DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a),
                        DECN ? 0u - a.nco_word : 0u - a.nco_word * (uint32_t)F,

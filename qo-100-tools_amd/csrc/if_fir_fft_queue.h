@@ -20,6 +20,12 @@
 // it for the workgroup: a wave that draws a block >= nblocks leaves at once, and a wave that finds a used-up group leaves
 // when that group already reaches the end.  Every wait is bounded: after Q_SPIN_LIMIT polls a wave leaves and counts a
 // fault (third word of the queue block) instead of spinning for ever.
+// TAIL (round 3, short launches only: queue_main_blocks): with two waves per SIMD a launch is a whole number of two-wave rounds
+// plus a remainder.  When the remainder is at most one block per SIMD the launcher keeps it out of the groups (nblocks_main < nblocks): after the last group every
+// SIMD's FIRST wave to arrive takes one tail block and the second wave leaves, so the last round runs one wave per SIMD
+// (a block then takes ~0.6 of its two-wave time) instead of two waves on some SIMDs and none on others.  Tail blocks are
+// handed out four at a time (one per SIMD of a workgroup) through a second global counter, first come first served: the
+// workgroups that finish their groups first get them.
 // One global atomic per QB blocks (a single address takes ~88 atomics/us; 70 k blocks in 0.5 ms would be 140/us), two
 // groups of slack before anybody needs its result.
 #pragma once
@@ -61,6 +67,10 @@ IF_FIR_Q_FN unsigned long long queue_entry(unsigned global_group, unsigned local
 //   void fault()                              count a bounded-wait expiry
 //   void pause()                              back off inside a wait loop
 //   unsigned wgs()                            workgroups of the launch
+//   unsigned tail_claim(unsigned simd)        LDS fetch-and-increment of the SIMD's tail claim counter
+//   unsigned long long tail_add()             LDS returning add of 1 on the workgroup's tail word
+//   unsigned long long tail_load() / void tail_store(v)
+//   unsigned tail_ticket()                    global fetch-and-increment of the launch's tail counter
 
 template <class P>
 IF_FIR_Q_FN bool queue_wait_entry(P &p, unsigned i, unsigned long long &e)
@@ -94,9 +104,42 @@ IF_FIR_Q_FN void queue_start(P &p)
     queue_fetch(p, Q_AHEAD);
 }
 
-// next block of this wave (>= nblocks: leave); *local_group (optional) receives the local group of the block
+// tail phase: at most one block per SIMD (see the header comment); tail word: 0 = nobody here yet, low byte = arrivals,
+// [63:32] = 1 + first tail block of this workgroup once the first arrival has drawn it
 template <class P>
-IF_FIR_Q_FN int64_t queue_take(P &p, int64_t nblocks, unsigned *local_group = nullptr)
+IF_FIR_Q_FN int64_t queue_tail(P &p, unsigned simd, int64_t nblocks_main, int64_t nblocks)
+{
+    if (p.tail_claim(simd) != 0)
+        return Q_NONE; // this SIMD's first wave has (or had) its tail block: the last round runs one wave per SIMD
+    unsigned long long w = p.tail_add();
+    if ((w & 0xffu) == 0)
+    {
+        const unsigned t = p.tail_ticket();
+        w = ((unsigned long long)(4u * t + 1u) << 32) | 1u;
+        p.tail_store(w);
+    }
+    else
+    {
+        unsigned spin = 0;
+        for (; spin < Q_SPIN_LIMIT && (w >> 32) == 0; spin++)
+        {
+            p.pause();
+            w = p.tail_load();
+        }
+        if ((w >> 32) == 0)
+        {
+            p.fault();
+            return Q_NONE;
+        }
+    }
+    const int64_t blk = nblocks_main + (int64_t)((unsigned)(w >> 32) - 1u) + simd;
+    return blk < nblocks ? blk : Q_NONE;
+}
+
+// next block of this wave (>= nblocks: leave); *local_group (optional) receives the local group of a block of the groups.
+// nblocks_main (a multiple of QB when < nblocks) = the blocks handed out in groups; the rest is the tail.
+template <class P>
+IF_FIR_Q_FN int64_t queue_take(P &p, unsigned simd, int64_t nblocks_main, int64_t nblocks, unsigned *local_group = nullptr)
 {
     for (unsigned spin = 0; spin < Q_SPIN_LIMIT; spin++)
     {
@@ -115,11 +158,14 @@ IF_FIR_Q_FN int64_t queue_take(P &p, int64_t nblocks, unsigned *local_group = nu
             }
             if (local_group)
                 *local_group = g;
-            return (int64_t)gg * QB + j;
+            const int64_t blk = (int64_t)gg * QB + j;
+            if (blk < nblocks_main)
+                return blk;
+            return nblocks_main < nblocks ? queue_tail(p, simd, nblocks_main, nblocks) : Q_NONE;
         }
-        // the group is used up.  If it already reaches the end of the stream no later group is in range (ordered tickets)
-        if ((int64_t)gg * QB + QB - 1 >= nblocks)
-            return Q_NONE;
+        // the group is used up.  If it already reaches the end of the groups no later group is in range (ordered tickets)
+        if ((int64_t)gg * QB + QB - 1 >= nblocks_main)
+            return nblocks_main < nblocks ? queue_tail(p, simd, nblocks_main, nblocks) : Q_NONE;
         // otherwise wait (without adding again) until the taker of its last slot has installed the next group
         for (; spin < Q_SPIN_LIMIT; spin++)
         {
@@ -131,6 +177,18 @@ IF_FIR_Q_FN int64_t queue_take(P &p, int64_t nblocks, unsigned *local_group = nu
     }
     p.fault();
     return Q_NONE;
+}
+
+// The launcher's split of a launch into groups and tail for `wgs` workgroups (4 SIMDs, two waves per SIMD each): returns
+// nblocks_main.  p = whole two-wave rounds; the remainder goes to the tail only if it is at most one block per SIMD, and only
+// in SHORT launches (p <= Q_TAIL_MAX_ROUNDS): measured on MI355X (profiles/r03_queue_tail_ab.txt) the tail shortens a
+// 2^24-sample call by 14 % (2.13 blocks per wave) and a 2^25-sample one by 6 %, does nothing from 8 rounds on, and costs
+// 1.5 % at 34 rounds, where the spread between fast and slow waves is larger than the remainder.
+constexpr int64_t Q_TAIL_MAX_ROUNDS = 6;
+IF_FIR_Q_FN int64_t queue_main_blocks(int64_t nblocks, int64_t wgs)
+{
+    const int64_t simds = 4 * wgs, p = nblocks / (2 * simds), rem = nblocks - 2 * p * simds;
+    return (p >= (int64_t)Q_AHEAD && p <= Q_TAIL_MAX_ROUNDS && rem > 0 && rem <= simds) ? 2 * p * simds : nblocks;
 }
 
 // initial LDS image of workgroup `wg`: the current-group word (static_first: local group 1 = global group wgs + wg, group 0

@@ -51,7 +51,7 @@ struct LaunchArgs
     const void *fft_tables; // device, FFT_TABLE_FLOATS floats (overlap-save backend) or nullptr
     const void *fft_tables_b; // second partition's tables (3074..4096 taps) or nullptr
     int in_shift;             // overlap-save kernel: the input is read delayed by this many samples (second partition)
-    void *queue; // device, 16 bytes: atomic run queue of the persistent kernel (zeroed by the launcher)
+    void *queue; // device, 32 bytes: ticket counters of the persistent kernels (words 0-3, zeroed by the launcher) + fault count
     int diag;  // development diagnostics for the FFT kernel (0 in production)
     int grid_limit; // FFT backend: at most this many workgroups (0 = one per CU); same results, used by the queue tests
     void *dbg; // optional diagnostic stamp buffer (8192 x 4 x u64) or nullptr

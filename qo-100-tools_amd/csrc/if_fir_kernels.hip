@@ -733,7 +733,7 @@ static hipError_t launch_wave(const LaunchArgs &a, int run_len_arg)
     }
     if (a.queue_valid)
         *a.queue_valid = false; // the overlap-save launcher keeps a running ticket base on the same counter
-    hipError_t e = hipMemsetAsync(a.queue, 0, 8, a.stream); // run queue: re-zeroed before every launch (word 2 = fault count, kept)
+    hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream); // run queue: re-zeroed before every launch (word 4 = fault count, kept)
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, a.stream, reinterpret_cast<const f2 *>(a.in),

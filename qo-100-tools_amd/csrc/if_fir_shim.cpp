@@ -323,8 +323,8 @@ static uint8_t init_common(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t u
     INIT_TRY(hipMalloc((void **)&ctx->d_taps, sizeof(float) * taps_padded));
     INIT_TRY(hipMemset(ctx->d_taps, 0, sizeof(float) * taps_padded));
     INIT_TRY(hipMemcpy(ctx->d_taps, pfTaps, sizeof(float) * tap_floats, hipMemcpyHostToDevice));
-    INIT_TRY(hipMalloc(&ctx->d_queue, 16));
-    INIT_TRY(hipMemset(ctx->d_queue, 0, 16));
+    INIT_TRY(hipMalloc(&ctx->d_queue, 32));
+    INIT_TRY(hipMemset(ctx->d_queue, 0, 32));
     ctx->hist_len = hist_len_for((int)ulTaps);
     const size_t hist_bytes = 8 * (size_t)(ctx->hist_len > 0 ? ctx->hist_len : 1);
     for (int i = 0; i < 2; i++)
@@ -502,11 +502,11 @@ static uint8_t check_queue_faults(if_fir_ctx *ctx)
     // on the context's stream (callers have just synchronized it): a copy on the null stream would also wait for every
     // blocking stream of the process
     uint32_t faults = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&faults, static_cast<const char *>(ctx->d_queue) + 8, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&faults, static_cast<const char *>(ctx->d_queue) + 16, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (faults)
     {
-        (void)hipMemsetAsync(static_cast<char *>(ctx->d_queue) + 8, 0, 4, ctx->stream);
+        (void)hipMemsetAsync(static_cast<char *>(ctx->d_queue) + 16, 0, 4, ctx->stream);
         set_err(ctx, "overlap-save block queue: %u bounded wait(s) expired since the last check; outputs of the calls in between "
                      "are incomplete (please report: this is a library defect)", faults);
         return 0;
@@ -888,14 +888,14 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
 }
 
-// bounded waits of the block queue that expired (if_fir_fft_queue.h): third word of the queue block
+// bounded waits of the block queue that expired (if_fir_fft_queue.h): word 4 of the queue block
 IF_FIR_API uint8_t if_fir_debug_queue_faults(if_fir_ctx_t *pCtx, uint32_t *pulFaults)
 {
     if (!pCtx || !pulFaults)
         return 0;
     HIP_TRY(pCtx, hipSetDevice(pCtx->device));
     HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
-    HIP_TRY(pCtx, hipMemcpy(pulFaults, static_cast<const char *>(pCtx->d_queue) + 8, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(pCtx, hipMemcpy(pulFaults, static_cast<const char *>(pCtx->d_queue) + 16, 4, hipMemcpyDeviceToHost));
     return 1;
 }
 

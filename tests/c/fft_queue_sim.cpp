@@ -21,9 +21,11 @@ struct Workgroup
 {
     std::atomic<unsigned long long> cur{0};
     std::atomic<unsigned long long> ring[Q_RING];
+    std::atomic<unsigned long long> tail{0};
+    std::atomic<unsigned> claim[4];
 };
 
-static std::atomic<unsigned> g_ticket{0}, g_faults{0};
+static std::atomic<unsigned> g_ticket{0}, g_faults{0}, g_tail_ticket{0};
 static unsigned g_wgs = 1;
 static bool g_delay_fetch = false;
 
@@ -41,6 +43,16 @@ struct HostQueue
         if (g_delay_fetch && ((*rng)() & 3) == 0)
             std::this_thread::sleep_for(std::chrono::microseconds(200 + (*rng)() % 400));
         return g_ticket.fetch_add(1, std::memory_order_relaxed);
+    }
+    unsigned tail_claim(unsigned simd) { return wg->claim[simd].fetch_add(1, std::memory_order_relaxed); }
+    unsigned long long tail_add() { return wg->tail.fetch_add(1, std::memory_order_relaxed); }
+    unsigned long long tail_load() { return wg->tail.load(std::memory_order_relaxed); }
+    void tail_store(unsigned long long v) { wg->tail.store(v, std::memory_order_relaxed); }
+    unsigned tail_ticket()
+    {
+        if (g_delay_fetch && ((*rng)() & 1) == 0)
+            std::this_thread::sleep_for(std::chrono::microseconds(100 + (*rng)() % 300));
+        return g_tail_ticket.fetch_add(1, std::memory_order_relaxed);
     }
     void fault() { g_faults.fetch_add(1); }
     void pause() { std::this_thread::yield(); }
@@ -69,7 +81,13 @@ int main(int argc, char **argv)
         wg[b].cur.store(queue_cur_init(b, g_wgs, true)); // local group 0 is taken statically
         for (unsigned i = 0; i < Q_RING; i++)
             wg[b].ring[i].store(queue_ring_init(i, b, g_wgs));
+        for (auto &c : wg[b].claim)
+            c.store(0);
     }
+    const int64_t nmain = queue_main_blocks(nblocks, g_wgs);
+    std::vector<std::atomic<int>> tail_per_simd(4 * g_wgs);
+    for (auto &t : tail_per_simd)
+        t.store(0);
     std::vector<std::atomic<int>> taken(nblocks > 0 ? nblocks : 1);
     for (auto &t : taken)
         t.store(0);
@@ -96,7 +114,9 @@ int main(int argc, char **argv)
                         std::this_thread::sleep_for(std::chrono::milliseconds(3)); // a wave that falls far behind its workgroup
                     else if ((r & 3) == 0)
                         std::this_thread::yield();
-                    blk = queue_take(q, nblocks);
+                    if (blk >= nmain && tail_per_simd[4 * b + (w & 3)].fetch_add(1) != 0)
+                        beyond.fetch_add(1);                 // two tail blocks on one SIMD of one workgroup: never
+                    blk = queue_take(q, w & 3, nmain, nblocks);
                 }
             });
     for (auto &t : waves)
@@ -110,9 +130,10 @@ int main(int argc, char **argv)
     }
     const unsigned tickets = g_ticket.load();
     const int64_t bound = groups + 2 * (int64_t)g_wgs;
-    const bool ok = missing == 0 && twice == 0 && g_faults.load() == 0 && (int64_t)tickets <= bound;
-    printf("nblocks %lld wgs %u seed %u delay %d: missing %lld twice %lld faults %u tickets %u (bound %lld) %s\n", (long long)nblocks,
-           g_wgs, seed, (int)g_delay_fetch, (long long)missing, (long long)twice, g_faults.load(), tickets, (long long)bound,
-           ok ? "OK" : "FAIL");
+    const bool ok = missing == 0 && twice == 0 && g_faults.load() == 0 && (int64_t)tickets <= bound && beyond.load() == 0 &&
+                    (int64_t)g_tail_ticket.load() <= (int64_t)g_wgs;
+    printf("nblocks %lld (groups %lld + tail %lld) wgs %u seed %u delay %d: missing %lld twice %lld faults %u tickets %u (bound %lld) "
+           "tail tickets %u %s\n", (long long)nblocks, (long long)nmain, (long long)(nblocks - nmain), g_wgs, seed, (int)g_delay_fetch,
+           (long long)missing, (long long)twice, g_faults.load(), tickets, (long long)bound, g_tail_ticket.load(), ok ? "OK" : "FAIL");
     return ok ? 0 : 1;
 }
