@@ -181,14 +181,14 @@ IF_FIR_Q_FN int64_t queue_take(P &p, unsigned simd, int64_t nblocks_main, int64_
 
 // The launcher's split of a launch into groups and tail for `wgs` workgroups (4 SIMDs, two waves per SIMD each): returns
 // nblocks_main.  p = whole two-wave rounds; the remainder goes to the tail only if it is at most one block per SIMD, and only
-// in SHORT launches (p <= Q_TAIL_MAX_ROUNDS): measured on MI355X (profiles/r03_queue_tail_ab.txt) the tail shortens a
+// in SHORT launches (1 <= p <= Q_TAIL_MAX_ROUNDS): measured on MI355X (profiles/r03_queue_tail_ab.txt) the tail shortens a
 // 2^24-sample call by 14 % (2.13 blocks per wave) and a 2^25-sample one by 6 %, does nothing from 8 rounds on, and costs
 // 1.5 % at 34 rounds, where the spread between fast and slow waves is larger than the remainder.
 constexpr int64_t Q_TAIL_MAX_ROUNDS = 6;
 IF_FIR_Q_FN int64_t queue_main_blocks(int64_t nblocks, int64_t wgs)
 {
     const int64_t simds = 4 * wgs, p = nblocks / (2 * simds), rem = nblocks - 2 * p * simds;
-    return (p >= (int64_t)Q_AHEAD && p <= Q_TAIL_MAX_ROUNDS && rem > 0 && rem <= simds) ? 2 * p * simds : nblocks;
+    return (p >= 1 && p <= Q_TAIL_MAX_ROUNDS && rem > 0 && rem <= simds) ? 2 * p * simds : nblocks;
 }
 
 // initial LDS image of workgroup `wg`: the current-group word (static_first: local group 1 = global group wgs + wg, group 0

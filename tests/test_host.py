@@ -243,11 +243,12 @@ def test_block_queue_kernel_code_under_host_simulation():
     # (blocks, workgroups, hold the ticket fetches back); several have a tail (a remainder of at most one block per SIMD that
     # is kept out of the groups and handed out one block per SIMD, in launches of at most 6 two-wave rounds): 70/4, 100/3, 130/4, 200/4
     cases = [(1, 4, 0), (3, 4, 0), (8, 4, 0), (9, 4, 0), (17, 1, 0), (64, 8, 0), (65, 8, 1), (70, 4, 1), (100, 3, 1), (130, 4, 1),
+             (33, 4, 1), (40, 4, 1), (17, 2, 1), (2185, 256, 1),      # one round of groups + a tail
              (200, 4, 0), (650, 4, 0), (1000, 6, 0), (1000, 6, 1), (2049, 8, 0), (4369, 5, 1), (8191, 8, 1), (69906, 8, 0)]
     for seed, (nblocks, wgs, delay) in enumerate(cases):
         run = subprocess.run([exe, str(nblocks), str(wgs), str(seed + 1), str(delay)], capture_output=True, text=True, timeout=300)
         assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
-        if (nblocks, wgs) in ((70, 4), (100, 3), (130, 4), (200, 4)):
+        if (nblocks, wgs) in ((70, 4), (100, 3), (130, 4), (200, 4), (33, 4), (40, 4), (17, 2), (2185, 256)):
             assert "+ tail 0)" not in run.stdout, run.stdout
         if (nblocks, wgs) in ((650, 4), (4369, 5), (69906, 8)):     # long launches: no tail phase
             assert "+ tail 0)" in run.stdout, run.stdout
