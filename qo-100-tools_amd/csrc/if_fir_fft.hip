@@ -541,6 +541,15 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // diag 512 (development: the fault path's test): the waves of workgroup 0 behave like waves whose bounded wait has expired --
+    // they count a fault and leave (the whole workgroup, ahead of its barrier), their blocks stay unwritten -- and the caller
+    // must be told (if_fir_synchronize)
+    if ((diag & 512) && blockIdx.x == 0)
+    {
+        if (lane == 0)
+            atomicAdd(queue + 4, 1u);
+        return;
+    }
     cf r[64];
     bool loaded = false; // the rows of `blk` are already in flight (issued by the prologue or the previous iteration's epilogue)
     // ---- first block: static (wave w of workgroup b takes block w of global group b), and its rows are requested BEFORE

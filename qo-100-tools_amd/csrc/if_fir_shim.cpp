@@ -507,6 +507,7 @@ static uint8_t check_queue_faults(if_fir_ctx *ctx)
     if (faults)
     {
         (void)hipMemsetAsync(static_cast<char *>(ctx->d_queue) + 16, 0, 4, ctx->stream);
+        ctx->queue_valid = false; // the ticket counters are in an unknown state: the next launch zeroes them itself
         set_err(ctx, "overlap-save block queue: %u bounded wait(s) expired since the last check; outputs of the calls in between "
                      "are incomplete (please report: this is a library defect)", faults);
         return 0;

@@ -1243,6 +1243,46 @@ def test_stream_capture_is_refused(fir, oracle, torch_cuda):
         assert l2 <= TOL and mx <= TOL
 
 
+def test_block_queue_fault_is_reported_to_the_caller(fir, oracle, torch_cuda):
+    """The overlap-save kernel's block queue bounds every wait; a wave whose wait expires leaves its blocks unwritten and counts
+    a fault.  That must never happen -- and if it does the caller has to hear about it.  Development launch 512 makes the
+    waves of workgroup 0 do exactly that (count a fault, leave): the launch ends with outputs missing, if_fir_synchronize
+    fails with the queue's message, and the same context filters correctly again afterwards.  (The bounded waits
+    themselves run in the host simulation of the queue code, tests/c/fft_queue_sim.cpp.)"""
+    torch = torch_cuda
+    n = 1 << 25
+    taps = fir.bpf_design(255)
+    x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+    old = os.environ.get("IF_FIR_DEBUG")
+    os.environ["IF_FIR_DEBUG"] = "1"
+    try:
+        with fir.IfFir(taps, 4, 0, dev=True) as f:
+            m = f.out_count(n)
+            good = torch.zeros(2 * m, dtype=torch.float32, device="cuda")
+            bad = torch.zeros(2 * m, dtype=torch.float32, device="cuda")
+            f.synth_device(x.data_ptr(), 0, n, 0)
+            assert f.process_device(x.data_ptr(), good.data_ptr(), n) == m
+            f.synchronize()
+            assert f.debug_queue_faults() == 0
+            f.reset()
+            f.set_tuning(1000000 + 512)
+            assert f.process_device(x.data_ptr(), bad.data_ptr(), n) == m     # asynchronous: the launch itself is accepted
+            with pytest.raises(fir.IfFirError, match="bounded wait"):
+                f.synchronize()
+            assert not torch.equal(good, bad) and int((bad.view(-1, 2).abs().sum(1) == 0).sum()) >= 960   # blocks left unwritten
+            f.set_tuning(0)
+            f.reset()
+            again = torch.zeros(2 * m, dtype=torch.float32, device="cuda")
+            assert f.process_device(x.data_ptr(), again.data_ptr(), n) == m
+            f.synchronize()
+            assert torch.equal(good, again)
+    finally:
+        if old is None:
+            os.environ.pop("IF_FIR_DEBUG", None)
+        else:
+            os.environ["IF_FIR_DEBUG"] = old
+
+
 def test_block_queue_counters_alternate_over_many_launches(fir, oracle):
     """Overlap-save launches draw block groups from one of two global counters and zero the other one for the launch
     behind them.  Many back-to-back calls on small grids (most blocks then come through the global counter) give the
