@@ -2,6 +2,8 @@
 seconds, so parity is checked (a) exactly on windows of the stream against the oracle, (b) through size-independent
 properties: one call ≡ two calls at an odd split (tile placement independence, history/phase carry), and a checksum
 of the whole output that must not depend on the split."""
+import os
+
 import numpy as np
 import pytest
 
@@ -284,3 +286,54 @@ def test_full_size_two_partition_filter(fir, oracle, gpu_ok, t, d):
         full[5:5 + t] = taps
         want = full[::d][:got.size // 2]
         assert np.max(np.abs(got[0::2] - want)) <= 1e-6 * np.max(np.abs(taps)) and np.max(np.abs(got[1::2])) <= 1e-6 * np.max(np.abs(taps))
+
+
+@pytest.mark.parametrize("n", [(1 << 23) + 777, (1 << 24) + 12_345, (1 << 25) + 1, 16_773_120])
+def test_mid_size_launches_with_the_tail_phase(fir, oracle, gpu_ok, n):
+    """Launches of 1 to 6 two-wave rounds hand the remainder out one block per SIMD (the block queue's tail phase, round 3;
+    16 773 120 samples = the multi-channel front's chunk): EVERY output against the direct-form kernel on the same input,
+    a window at the very end (the tail blocks) against the float64 oracle, and the launch without the tail phase
+    (development variant) bit for bit."""
+    import torch
+    torch.cuda.set_device(0)
+    t, d = 255, 4
+    taps = fir.bpf_design(t)
+    old = os.environ.get("IF_FIR_DEBUG")
+    os.environ["IF_FIR_DEBUG"] = "1"
+    try:
+        with fir.IfFir(taps, d, 0, dev=True) as f:
+            x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+            m = f.out_count(n)
+            y = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            f.synth_device(x.data_ptr(), 0, n, 3)
+            assert f.get_backend() == fir.BACKEND_HIP_FFT
+            assert f.process_device(x.data_ptr(), y.data_ptr(), n) == m
+            f.synchronize()
+            assert f.debug_queue_faults() == 0
+            w = 8192
+            start = (n - w) & ~3
+            xs = x[2 * (start - (t - 1)):].cpu().numpy()
+            hist = xs[:2 * (t - 1)].copy()
+            ref = oracle.fir_f64(taps, xs[2 * (t - 1):], d, hist, start)
+            got = y[2 * (start // d):].cpu().numpy()
+            l2, mx = oracle.err_metrics(got, ref)
+            assert l2 <= 1e-6 and mx <= 1e-6, (l2, mx)
+            f.reset()
+            f.set_tuning(1000000 + 256)          # the same launch without the tail phase: the same bits
+            y2 = torch.empty_like(y)
+            assert f.process_device(x.data_ptr(), y2.data_ptr(), n) == m
+            f.synchronize()
+            assert torch.equal(y, y2)
+            f.set_tuning(0)
+            f.reset()
+            f.set_backend(fir.BACKEND_HIP_DIRECT)
+            assert f.process_device(x.data_ptr(), y2.data_ptr(), n) == m
+            f.synchronize()
+            scale = y2.abs().max().item()
+            assert scale > 0.1 and (y - y2).abs().max().item() <= 2e-6 * scale
+    finally:
+        if old is None:
+            os.environ.pop("IF_FIR_DEBUG", None)
+        else:
+            os.environ["IF_FIR_DEBUG"] = old
