@@ -199,17 +199,17 @@ __global__ __launch_bounds__(512, 2) void k_energy(const cf *__restrict__ tab, c
             else if constexpr (VAR == V_ADD || VAR == V_MUL || VAR == V_FMA)
             {
                 // 110 independent packed instructions: sources t[0..7] (never written: the values stay the random inputs),
-                // destinations t[8..15]
+                // destinations t[8..15] ("+v": kept in eight distinct registers)
 #pragma unroll
                 for (int k = 0; k < 110; k++)
                 {
                     const int a = 8 + (k & 7), b = (k + 3) & 7, c = (k + 5) & 7, d = (k + 6) & 7;
                     if (VAR == V_ADD)
-                        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(t[a]) : "v"(t[b]), "v"(t[c]));
+                        asm volatile("v_pk_add_f32 %0, %1, %2" : "+v"(t[a]) : "v"(t[b]), "v"(t[c]));
                     else if (VAR == V_MUL)
-                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t[a]) : "v"(t[b]), "v"(t[c]));
+                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "+v"(t[a]) : "v"(t[b]), "v"(t[c]));
                     else
-                        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t[a]) : "v"(t[b]), "v"(t[c]), "v"(t[d]));
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "+v"(t[a]) : "v"(t[b]), "v"(t[c]), "v"(t[d]));
                 }
             }
             if constexpr (VAR == V_OLD || VAR == V_NEW || VAR == V_SCALE)
