@@ -98,7 +98,8 @@ uint8_t if_fir_set_input_format(if_fir_ctx_t *pCtx, uint32_t ulFormat);
  * set since the last reset (the phase is a function of the absolute index).  Overlap-save and generic kernels only. */
 uint8_t if_fir_set_nco(if_fir_ctx_t *pCtx, double dFreq);
 uint8_t if_fir_get_nco(const if_fir_ctx_t *pCtx, double *pdFreq);
-/* expert knob: pick a schedule variant of the direct-form kernels (0 = default, 1..9).  Variants change
+/* expert knob: pick a schedule variant of the direct-form kernels (0 = default, 1..6: workgroup kernel v1 in
+ * three tile shapes, the wave kernel with 8- or 16-byte LDS reads and 2 / 4 / 8 tiles per run).  Variants change
  * speed only.  Everything else (diagnostic launches, grid limits, test hooks) lives in the development library, see
  * if_fir_debug.h.
  * Environment: IF_FIR_RCCL_LIBRARY = path of the library providing the nccl* entry points of the multi-channel front

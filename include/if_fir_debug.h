@@ -5,8 +5,6 @@
  *
  * Development tuning variants of if_fir_set_tuning() (dev library only; the diagnostic ones additionally need
  * IF_FIR_DEBUG=1 in the environment because their results are WRONG by construction):
- *   10             direct-form kernel, 255 taps / 4: the generated walk WITHOUT its tap-block drains (IF_FIR_DEBUG=1; a timing
- *                  study that bounds what any other way of delivering the taps could gain; results are not guaranteed)
  *   2000 + k       at most k workgroups for the overlap-save kernel: same results; lets small inputs run through every
  *                  stage of the block queue (tests/test_gpu_parity.py)
  *   1000 + bits    diagnostic launches of the overlap-save kernel (IF_FIR_DEBUG=1): 1 skip the global loads, 2 skip the

@@ -1050,7 +1050,13 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 // row offset sat in an SGPR the compiler placed no wait state between the store and the next (inline-asm) VALU
                 // write of its data registers, and the second dword of the data arrived corrupted now and then (found by the
                 // chunked-equals-unchunked GPU test; tools/diag_dec2.py).  In this form it inserts the s_nop the hazard needs.
+                // tools/check_store_hazard.py scans every unit's disassembly for the hazard at build time (csrc/Makefile);
+                // IF_FIR_FFT_HAZARD_PROBE=1 compiles the old form (tests/test_host.py: the scanner must flag it).
+#if defined(IF_FIR_FFT_HAZARD_PROBE) && IF_FIR_FFT_HAZARD_PROBE == 1
+                __builtin_amdgcn_raw_buffer_store_b128(w, osrd, (unsigned)lane * 16u, (mu0 - MU0_FIRST) * 1024, IF_FIR_FFT_STORE_AUX);
+#else
                 __builtin_amdgcn_raw_buffer_store_b128(w, osrd, vo128, 0, IF_FIR_FFT_STORE_AUX);
+#endif
                 vo128 += 1024u;
                 asm volatile("" : "+v"(vo128)); // one running offset register, not 15 precomputed ones
             }
@@ -1658,9 +1664,15 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
     }
 }
 
+#ifdef IF_FIR_FFT_HAZARD_PROBE // (tests/test_host.py: one instantiation, the decimate-by-2 tail with its 16-byte stores)
+template __global__ void fir_fft_kernel<IF_FIR_FFT_ROWS, true, false, false, 2, false, false>(
+    const f2v *, f2v *, const f2v *, const f2v *, int, int64_t, int32_t, int64_t, int64_t, int64_t, unsigned int *,
+    unsigned long long *, int32_t, uint32_t, uint32_t, ChanArgs, uint32_t, void *, int32_t, int32_t, int64_t, int32_t);
+#else
 template hipError_t launch_fft_rows<IF_FIR_FFT_ROWS>(const LaunchArgs &a);
+#endif
 
-#if IF_FIR_FFT_ROWS == 32
+#if IF_FIR_FFT_ROWS == 32 && !defined(IF_FIR_FFT_HAZARD_PROBE)
 // Filters of 3074..4096 taps: h = (h_a, h_b) with 2048 taps in h_a.  Launch 1: y = h_a * x (writes the history);
 // launch 2: y += h_b * x(n - 2048): the same kernel with h_b's table, reading the input FFT_PART samples late and adding
 // its result to what launch 1 stored (ACC).  Both are the 32-row (2049-tap) kernel; an even decimation runs behind the

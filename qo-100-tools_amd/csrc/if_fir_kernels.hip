@@ -265,10 +265,6 @@ struct AsmWalk;
     };
 IF_FIR_ASM_WALK(255, 4, 8, 32, 0, walk_asm_T255_D4_R8_S32)
 IF_FIR_ASM_WALK(255, 4, 8, 32, 2, walk_asm_T255_D4_R8_S32_b128)
-IF_FIR_ASM_WALK(255, 4, 8, 32, 3, walk_asm_T255_D4_R8_S32_b128_w2)   // round 3: no LDS read in the 2 / 3 steps ahead of a tap drain
-IF_FIR_ASM_WALK(255, 4, 8, 32, 4, walk_asm_T255_D4_R8_S32_b128_w3)
-IF_FIR_ASM_WALK(255, 4, 8, 32, 5, walk_asm_T255_D4_R8_S32_b128_q4w2)
-IF_FIR_ASM_WALK(255, 4, 8, 32, 6, walk_asm_T255_D4_R8_S32_b128_nodrain) // timing study: tap blocks used without the drain (dev variant 10)
 IF_FIR_ASM_WALK(127, 4, 8, 32, 0, walk_asm_T127_D4_R8_S32)
 
 typedef __attribute__((address_space(3))) char lds_char_t;
@@ -758,10 +754,6 @@ hipError_t launch_fir(const LaunchArgs &a, int variant)
             case 4: return launch_wave<255, 4, 8, 32, 0>(a, 4);
             case 5: return launch_wave<255, 4, 8, 32, 2>(a, 8);
             case 6: return launch_wave<255, 4, 8, 32, 2>(a, 2);
-            case 7: return launch_wave<255, 4, 8, 32, 3>(a, 4);
-            case 8: return launch_wave<255, 4, 8, 32, 4>(a, 4);
-            case 9: return launch_wave<255, 4, 8, 32, 5>(a, 4);
-            case 10: return launch_wave<255, 4, 8, 32, 6>(a, 4); // development library only (if_fir_set_tuning refuses > 9 otherwise)
             default: return launch_wave<255, 4, 8, 32, 2>(a, 4);
             }
         }

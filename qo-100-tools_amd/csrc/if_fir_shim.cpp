@@ -456,16 +456,16 @@ IF_FIR_API uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant)
 #ifdef IF_FIR_DEVELOPMENT
     // (if_fir_debug.h) diagnostic launches of the overlap-save kernel skip loads or stores (WRONG results, for timing
     // studies) and 4000 injects a failure: refused unless the process runs with IF_FIR_DEBUG=1
-    if (((ulVariant >= 1000 && ulVariant < 2000) || ulVariant == 4000 || ulVariant >= 1000000 || ulVariant == 10) && !debug_enabled())
+    if (((ulVariant >= 1000 && ulVariant < 2000) || ulVariant == 4000 || ulVariant >= 1000000) && !debug_enabled())
     {
         set_err(pCtx, "if_fir_set_tuning: variant %u is a diagnostic launch (wrong results); set IF_FIR_DEBUG=1 to allow it",
                 ulVariant);
         return 0;
     }
 #else
-    if (ulVariant > 9)
+    if (ulVariant > 6)
     {
-        set_err(pCtx, "if_fir_set_tuning: variant %u is not a schedule variant (0..9); development variants exist in "
+        set_err(pCtx, "if_fir_set_tuning: variant %u is not a schedule variant (0..6); development variants exist in "
                       "libif_fir_dev.so only (if_fir_debug.h)", ulVariant);
         return 0;
     }

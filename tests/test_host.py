@@ -278,6 +278,53 @@ def test_no_overlap_save_instantiation_spills():
         assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
 
 
+def _hazard_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(ROOT, "tools", "check_store_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_wide_store_hazard_scanner_flags_the_round_3_form_and_passes_the_build():
+    """a store of more than 8 bytes followed too closely by a VALU write of its data registers corrupted
+    outputs now and then in round 3 (16-byte store with the row offset in an SGPR: the compiler places no wait state).  The
+    disassembly of every device object of the library is scanned (tools/check_store_hazard.py, also a build step); the
+    scanner must flag the old form, compiled here from the kernel source with IF_FIR_FFT_HAZARD_PROBE=1, and pass the
+    current one (=2: the same single instantiation) and everything the build produced."""
+    import subprocess
+    import tempfile
+    tool = _hazard_tool()
+    # synthetic snippets: 0 and 1 wait states are violations, 2 are enough; an s_nop 1 counts two; a non-overlapping write is fine
+    st = "\tbuffer_store_dwordx4 v[10:13], v40, s[36:39], s5 offen nt\n"
+    assert tool.scan_text(st + "\tv_pk_add_f32 v[12:13], v[2:3], v[4:5]\n")
+    assert tool.scan_text(st + "\tv_add_u32_e32 v40, 0x400, v40\n\tv_mov_b32_e32 v10, 0\n")
+    assert not tool.scan_text(st + "\tv_add_u32_e32 v40, 0x400, v40\n\ts_nop 0\n\tv_mov_b32_e32 v10, 0\n")
+    assert not tool.scan_text(st + "\ts_nop 1\n\tv_pk_mul_f32 v[10:11], v[2:3], v[4:5]\n")
+    assert not tool.scan_text(st + "\tv_pk_add_f32 v[14:15], v[2:3], v[4:5]\n\tv_pk_add_f32 v[8:9], v[2:3], v[4:5]\n")
+    assert tool.scan_text("\tglobal_store_dwordx4 v[2:3], v[10:13], off\n\tv_permlane32_swap_b32_e32 v1, v11\n")
+    csrc = os.path.join(ROOT, "qo-100-tools_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        for probe, expect_bad in ((1, True), (2, False)):
+            out = os.path.join(td, "probe%d.s" % probe)
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                                   "-I" + csrc, "-DIF_FIR_FFT_ROWS=4", "-DIF_FIR_FFT_HAZARD_PROBE=%d" % probe, "-S", "--cuda-device-only",
+                                   os.path.join(csrc, "if_fir_fft.hip"), "-o", out], stderr=subprocess.DEVNULL)
+            text = open(out).read()
+            assert tool.count_wide_stores(text) >= 12, "the probe no longer holds the 16-byte stores of the decimate-by-2 tail"
+            bad = tool.scan_text(text, "probe%d" % probe)
+            assert bool(bad) == expect_bad, (probe, bad[:3])
+    objs = ["if_fir_fft_r%d.o" % r for r in (2, 4, 8, 16, 32, 48)] + ["if_fir_kernels.o", "wb_detect.o"]
+    for o in objs:
+        path = os.path.join(csrc, o)
+        if o == "if_fir_fft_r2.o" and not os.path.exists(path):
+            continue
+        assert os.path.exists(path), "build() first: %s" % o
+        text = tool.disassemble(path)
+        assert tool.count_wide_stores(text) > 0, o
+        assert not tool.scan_text(text, o), o
+
+
 def test_bench_line_contract_on_the_committed_run():
     """The bench.py JSON line of the last profiled run (profiles/*_bench.json, produced on the GPU box) carries every
     field the driver's contract names, with the right types, and its numbers are mutually consistent."""

@@ -207,16 +207,29 @@ CONFIGS = [
     # (T, D, R, SEG, [(suffix, Q, U), ...])
     # only what the library launches: the decimating walks (the D = 1 wave-kernel walks of round 1 were reachable through
     # tuning variants only -- the D = 1 configurations run the compiler-scheduled workgroup kernel -- and were removed)
-    (255, 4, 8, 32, [("", 4, 1), ("_b128", 2, 2), ("_b128_w2", 3, 2, 2), ("_b128_w3", 3, 2, 3), ("_b128_q4w2", 4, 2, 2),
-                     ("_b128_nodrain", 2, 2, 1, True)]),
+    # (round 4: the drain-shadow walks _b128_w2 / _w3 / _q4w2 and the no-drain timing study of round 3 measured nothing --
+    # profiles/r03_direct_form_walks.txt -- and are no longer emitted; `--experiments` brings them back into a scratch header)
+    (255, 4, 8, 32, [("", 4, 1), ("_b128", 2, 2)]),
     (127, 4, 8, 32, [("", 4, 1)]),
+]
+
+
+EXPERIMENTS = [
+    # closed experiments of round 3 (never part of the library): drain shadow W = 2, 3, deeper prefetch, and the walk without
+    # its tap drains (WRONG results by construction, a timing bound)
+    (255, 4, 8, 32, [("_b128_w2", 3, 2, 2), ("_b128_w3", 3, 2, 3), ("_b128_q4w2", 4, 2, 2), ("_b128_nodrain", 2, 2, 1, True)]),
 ]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=OUT)
+    ap.add_argument("--experiments", action="store_true", help="also emit the closed round-3 experiment walks (use with --out)")
     args = ap.parse_args()
+    if args.experiments:
+        if os.path.abspath(args.out) == os.path.abspath(OUT):
+            ap.error("--experiments needs --out <scratch header>: the library's header holds only what it launches")
+        CONFIGS.extend(EXPERIMENTS)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         f.write("// GENERATED by tools/gen_walk.py — do not edit; regenerate with `python tools/gen_walk.py`.\n")
