@@ -187,7 +187,7 @@ uint8_t if_fir_mc_reset(if_fir_mc_ctx_t *pCtx);
 uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ulFormat);
 /* rank 0: ppDevIn[c] / ppDevOut[c] = device pointers on rank 0's GPU for every channel; other ranks may pass NULL.
  * Synchronous: returns when this rank's part (transfers and filters) has finished.  *pullOutSamples: per channel.
- * A failing filter on any rank makes the call fail on that rank AND on rank 0 (the other ranks complete normally; the
+ * A failing filter on any rank (or an expired wait of its block queue) makes the call fail on that rank AND on rank 0 (the other ranks complete normally; the
  * transfer protocol is always run to its end, nobody is left waiting); the channel streams are then out of step:
  * call if_fir_mc_reset() on every rank before the next call.  After an RCCL failure the communicator is aborted and the
  * context refuses further calls (destroy it and create a new one); the peers notice through the communicator's
@@ -196,13 +196,16 @@ uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ulFormat);
  * loopback, one process playing all ranks -- no multi-GPU node was available to the build). */
 uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDevIn, void *const *ppDevOut,
                                  uint64_t ullSamples, uint64_t *pullOutSamples);
-/* chunk length of the following calls: 0 = default (16 773 120 samples; with one rank: never split), UINT64_MAX = never split, otherwise a multiple of
- * 215 040 samples (the lcm of the overlap-save block advances).  The library rounds it up to a multiple of twice the
- * decimation and, where the kernel's block grid follows the decimation phase (every even decimation, <= 3073 taps), makes the first chunk of an
- * off-phase call that many samples longer: the blocks of a chunked call are then the blocks of an unchunked one and the
- * results are bit-identical whatever the chunk and whatever the phase (channels on the overlap-save backend, AUTO's
- * pick).  Every rank must make the same call. */
+/* chunk length of the following calls: 0 = default (about 2^24 samples; with one rank: never split), UINT64_MAX = never split,
+ * otherwise a request in samples.  The library rounds the request to the nearest multiple of the context's UNIT = lcm(block
+ * advance of the filter's overlap-save kernel -- 3968, 3840, 3584, 3072, 2048 or 1024 samples --, twice the decimation) and,
+ * where the kernel's block grid follows the decimation phase (every even decimation), makes the first chunk of an off-phase call
+ * that many samples longer: the blocks of a chunked call are then the blocks of an unchunked one and the results are
+ * bit-identical whatever the chunk and whatever the phase.  Calls are split on the overlap-save backend (AUTO's pick) only: with a
+ * channel switched to another backend a call that would be split is refused.  Every rank must make the same call.
+ * if_fir_mc_get_chunk_samples reports the chunk in effect (0 = not split) and the unit. */
 uint8_t if_fir_mc_set_chunk_samples(if_fir_mc_ctx_t *pCtx, uint64_t ullChunk);
+uint8_t if_fir_mc_get_chunk_samples(const if_fir_mc_ctx_t *pCtx, uint64_t *pullChunk, uint64_t *pullUnit);
 /* the single-channel context behind a channel this rank owns (NULL otherwise), e.g. for if_fir_set_backend() */
 if_fir_ctx_t *if_fir_mc_channel_ctx(if_fir_mc_ctx_t *pCtx, uint32_t ulChannel);
 const char *if_fir_mc_last_error(const if_fir_mc_ctx_t *pCtx);

@@ -530,6 +530,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4),
                   "decimating tails: 1, 2, 3, or the bank at 4, 8, 16");
     static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
+    // 2 overlap rows (<= 129 taps, round 4): the full-rate pipeline only -- the decimating tails drop whole 64-output rows of the
+    // fs/F-rate block (OVL_ROWS / 4, / 2, ...), which 128 samples are not
+    static_assert(OVL_ROWS >= 4 || (!DEC4 && !ACC), "2 overlap rows: full-rate pipeline (D = 1, odd D) only");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
@@ -1505,7 +1508,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     const int64_t wgs = sch.wgs;
     // groups and tail (if_fir_fft_queue.h): a remainder of at most one block per SIMD is kept out of the groups; diag 256
     // (development) switches the tail off
-    const int64_t nblocks_main = (a.diag & 256) ? nblocks : queue_main_blocks(nblocks, wgs);
+    // (diag 2048, development: the tail phase in launches of up to 16 two-wave rounds)
+    const int64_t nblocks_main = (a.diag & 256) ? nblocks : queue_main_blocks(nblocks, wgs, (a.diag & 2048) ? 16 : Q_TAIL_MAX_ROUNDS);
     // two global counters used alternately: a launch draws from one and zeroes the other for the launch behind it
     // (same stream, so it has finished before that one starts); after anybody else touched the words, start over
     uint32_t qsel = 0;
@@ -1572,11 +1576,24 @@ bool fft_two_partitions(int T)
     return T > 3073;
 }
 
-int fft_overlap_rows(int T)
+// Overlap rows of the (taps, decimation) pair.  Round 4: filters of at most 129 taps on the full-rate pipeline (D = 1 and the odd
+// decimations, which run it with a selecting store) discard 2 rows only: L = 3968.  2^26 samples are then 16 913 blocks = 8
+// two-wave rounds of the 2048 waves + a tail-phase round (with 4 rows: 17 477 blocks = 8.53 per wave, and the waves with 8 blocks
+// waited for those with 9: 12 % of that launch, DESIGN.md §3.4 finding 11).
+int fft_overlap_rows(int T, int D)
 {
     if (fft_two_partitions(T))
         return 32; // each partition runs the 32-row kernel
+    if (T - 1 <= 128 && !fft_tail(T, D, nullptr, nullptr))
+        return 2;
     return (T - 1 <= 256) ? 4 : (T - 1 <= 512) ? 8 : (T - 1 <= 1024) ? 16 : (T - 1 <= 2048) ? 32 : 48;
+}
+
+// new input samples per block of the overlap-save kernel for this filter: streams cut at multiples of it (and of the
+// decimation) give bit-identical results to the unsplit stream (the multi-channel front's chunk unit)
+int fft_block_advance(int T, int D)
+{
+    return fft_two_partitions(T) ? FFT_N - FFT_PART : FFT_N - 64 * fft_overlap_rows(T, D);
 }
 
 #endif
@@ -1589,6 +1606,9 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
 {
     int F = 1;
     const bool tail = fft_tail(a.T, a.D, &F, nullptr);
+    const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
+    if constexpr (ROWS >= 4)
+    {
     if (a.chan)
     {
         // the filter bank (decimation 4, 8, 16)
@@ -1614,7 +1634,6 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             }
         return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 4>(a) : launch_fft_t<ROWS, true, false, false, 4>(a);
     }
-    const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
     if (a.D == 2 && !a.no_fold) // frequency-domain fold + 2048-point inverse (round 3)
         switch (key)
         {
@@ -1647,6 +1666,9 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
         case 2: return launch_fft_t<ROWS, true, true, false, 1>(a);
         default: return launch_fft_t<ROWS, true, true, true, 1>(a);
         }
+    }
+    else if (a.chan || (tail && !a.no_fold))
+        return hipErrorInvalidConfiguration; // 2 overlap rows: full-rate pipeline only (fft_overlap_rows never sends a tail here)
     if (a.D == 1)
         switch (key)
         {
@@ -1729,8 +1751,13 @@ hipError_t launch_fft(const LaunchArgs &a)
         return hipErrorInvalidConfiguration;
     if (fft_two_partitions(a.T))
         return launch_fft_two_partitions(a);
-    switch (fft_overlap_rows(a.T))
+    // (the filter bank's decimations are even: never 2 rows)
+    int rows = fft_overlap_rows(a.T, a.D);
+    if (rows == 2 && (a.diag & 1024)) // development (A/B runs): the 4-row kernel for short filters as before round 4
+        rows = 4;
+    switch (rows)
     {
+    case 2: return launch_fft_rows<2>(a);
     case 4: return launch_fft_rows<4>(a);
     case 8: return launch_fft_rows<8>(a);
     case 16: return launch_fft_rows<16>(a);

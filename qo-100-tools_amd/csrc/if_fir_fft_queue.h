@@ -185,10 +185,10 @@ IF_FIR_Q_FN int64_t queue_take(P &p, unsigned simd, int64_t nblocks_main, int64_
 // 2^24-sample call by 14 % (2.13 blocks per wave) and a 2^25-sample one by 6 %, does nothing from 8 rounds on, and costs
 // 1.5 % at 34 rounds, where the spread between fast and slow waves is larger than the remainder.
 constexpr int64_t Q_TAIL_MAX_ROUNDS = 6;
-IF_FIR_Q_FN int64_t queue_main_blocks(int64_t nblocks, int64_t wgs)
+IF_FIR_Q_FN int64_t queue_main_blocks(int64_t nblocks, int64_t wgs, int64_t max_rounds = Q_TAIL_MAX_ROUNDS)
 {
     const int64_t simds = 4 * wgs, p = nblocks / (2 * simds), rem = nblocks - 2 * p * simds;
-    return (p >= 1 && p <= Q_TAIL_MAX_ROUNDS && rem > 0 && rem <= simds) ? 2 * p * simds : nblocks;
+    return (p >= 1 && p <= max_rounds && rem > 0 && rem <= simds) ? 2 * p * simds : nblocks;
 }
 
 // initial LDS image of workgroup `wg`: the current-group word (static_first: local group 1 = global group wgs + wg, group 0

@@ -130,7 +130,8 @@ hipError_t launch_fft(const LaunchArgs &a);
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale, float *tables,
                       int bank = 0);
 
-int fft_overlap_rows(int T);
+int fft_overlap_rows(int T, int D);
+int fft_block_advance(int T, int D); // new input samples per block: the unit at which a stream can be cut without changing a bit
 // decimating tail of (T, D): D = F * sub, F = 2 or 4 the tail's own decimation (false, F = 1: full-rate kernel + selecting store)
 bool fft_tail(int T, int D, int *pF, int *pSub);
 // history buffers hold the last `hist_len` samples of the stream (>= T-1; hist_in/hist_out: whole buffers)

@@ -97,10 +97,18 @@ RcclApi *rccl()
 
 thread_local char g_mc_init_err[256] = "";
 
-// chunks of a call: multiples of the lcm of the overlap-save block advances (see the transfer plan below)
-constexpr uint64_t MC_CHUNK_UNIT = 215040;
-constexpr uint64_t MC_CHUNK_DEFAULT = 78 * MC_CHUNK_UNIT; // 16 773 120 samples, ~2^24
+// chunks of a call: multiples of THIS filter's block advance and of twice its decimation (mc_chunk_unit, see the transfer plan
+// below); the default request is ~2^24 samples
+constexpr uint64_t MC_CHUNK_DEFAULT = 16773120; // 78 x 215 040 (round 3's global unit, the lcm of the block advances then)
 } // namespace
+
+namespace if_fir
+{
+bool fft_tail(int T, int D, int *pF, int *pSub); // if_fir_fft.hip
+int fft_block_advance(int T, int D);
+}
+// internal to the library (if_fir_shim.cpp, hidden): device address of the context's queue fault counter
+extern "C" __attribute__((visibility("hidden"))) const uint32_t *if_fir_internal_fault_word(const if_fir_ctx_t *pCtx);
 
 struct if_fir_mc_ctx
 {
@@ -114,7 +122,10 @@ struct if_fir_mc_ctx
     uint32_t in_bytes = 8; // bytes per input sample (8 = float32 I,Q; 4 = int16 I,Q)
     uint64_t max_samples = 0;
     uint64_t consumed = 0;      // samples per channel since init/reset (every rank counts: sizes of the gather pieces)
-    uint64_t chunk_samples = 0; // transfer/filter chunk (multiple of MC_CHUNK_UNIT), 0 = whole call in one piece
+    uint64_t chunk_samples = 0; // requested transfer/filter chunk (mc_effective_chunk rounds it), 0 = whole call in one piece
+    double timeout_s = 300.0;   // IF_FIR_MC_TIMEOUT_S, read once at init
+    const uint32_t **d_faultp = nullptr; // device: the owned channels' queue fault counters (status word of the last group)
+    uint32_t n_faultp = 0;
     int device = 0;
     hipStream_t stream = nullptr;      // filters
     hipStream_t xfer_stream = nullptr; // RCCL transfers
@@ -131,7 +142,7 @@ struct if_fir_mc_ctx
     mutable char err[256] = "";
 };
 
-static uint64_t mc_slot_samples(uint64_t samples, uint64_t chunk, uint32_t decim);
+static uint64_t mc_slot_samples(uint64_t samples, uint64_t chunk, uint32_t decim, uint32_t taps);
 
 static void mc_err(const if_fir_mc_ctx *ctx, const char *fmt, ...)
 {
@@ -215,6 +226,8 @@ static void mc_free(if_fir_mc_ctx *ctx)
         (void)ctx->api->CommDestroy(ctx->comm);
     if (ctx->d_status)
         (void)hipFree(ctx->d_status);
+    if (ctx->d_faultp)
+        (void)hipFree(ctx->d_faultp);
     if (ctx->xfer_stream)
         (void)hipStreamDestroy(ctx->xfer_stream);
     if (ctx->stream)
@@ -335,7 +348,29 @@ IF_FIR_API uint8_t if_fir_mc_init(if_fir_mc_ctx_t **ppCtx, uint32_t ulChannels, 
         if (!if_fir_set_stream(ctx->fir[c], ctx->stream))
             MC_INIT_FAIL("if_fir_mc_init: channel %u: %s", c, if_fir_last_error(ctx->fir[c]));
     }
-    if (!mc_ensure_staging(ctx, mc_slot_samples(ullMaxSamples, ctx->chunk_samples, ulDecimation)))
+    {
+        const char *te = getenv("IF_FIR_MC_TIMEOUT_S");
+        if (te && atof(te) > 0)
+            ctx->timeout_s = atof(te);
+    }
+    if (transport)
+    {
+        // the owned channels' queue fault counters: folded into this rank's status word on the device (mc_status_kernel)
+        std::vector<const uint32_t *> fp;
+        for (uint32_t c = 0; c < ulChannels; c++)
+            if (ctx->fir[c])
+                fp.push_back(if_fir_internal_fault_word(ctx->fir[c]));
+        ctx->n_faultp = (uint32_t)fp.size();
+        if (!fp.empty())
+        {
+            e = hipMalloc(reinterpret_cast<void **>(&ctx->d_faultp), fp.size() * sizeof(void *));
+            if (e == hipSuccess)
+                e = hipMemcpy(ctx->d_faultp, fp.data(), fp.size() * sizeof(void *), hipMemcpyHostToDevice);
+            if (e != hipSuccess)
+                MC_INIT_FAIL("if_fir_mc_init: device %d: %s", lDevice, hipGetErrorString(e));
+        }
+    }
+    if (!mc_ensure_staging(ctx, mc_slot_samples(ullMaxSamples, ctx->chunk_samples, ulDecimation, ulTaps)))
     {
         snprintf(g_mc_init_err, sizeof(g_mc_init_err), "if_fir_mc_init: %s", ctx->err);
         mc_free(ctx);
@@ -424,8 +459,9 @@ IF_FIR_API uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ul
 // the next chunk is queued ahead of the gather of this one, so the links stay busy while the owners filter.  Inside a
 // group the operations between a pair of ranks are posted in channel order on both sides (RCCL matches them in order).
 // STATUS: every rank that owns a channel sends one 4-byte word (0 = its filters succeeded) to the root.
-// A chunk is a multiple of MC_CHUNK_UNIT = lcm of the overlap-save block advances (3840, 3584, 3072, 2048, 1024) so
-// that the blocks of a chunked call start at the same stream positions as those of an unchunked one: bit-identical.
+// A chunk is a multiple of the block advance of THIS filter's overlap-save kernel (3968, 3840, 3584, 3072, 2048 or 1024 samples,
+// if_fir::fft_block_advance) so that the blocks of a chunked call start at the same stream positions as those of an unchunked
+// one: bit-identical.  (Round 3 used one global unit, the lcm of all block advances.)
 
 enum : uint32_t
 {
@@ -466,18 +502,31 @@ static uint64_t mc_gcd(uint64_t a, uint64_t b)
 // The decimating tails of the overlap-save kernel (if_fir::fft_tail: decimation 2, 4, 8, 16 and the multiples of 4, 8, 16 that keep
 // every sub-th tail output; <= 3073 taps) anchor their block grid at the call's first OUTPUT (n0 samples into the call when the
 // stream position is off-phase); every other kernel anchors it at the call's first sample.
-namespace if_fir
-{
-bool fft_tail(int T, int D, int *pF, int *pSub); // if_fir_fft.hip
-}
 static bool mc_grid_follows_phase(uint32_t taps, uint32_t decim)
 {
     return if_fir::fft_tail((int)taps, (int)decim, nullptr, nullptr);
 }
 
-// Chunk table of a call.  The effective chunk is the least common multiple of the requested chunk (a multiple of
-// MC_CHUNK_UNIT, the lcm of the block advances) and 2 D: every chunk then produces an even number of outputs whatever the
-// phase, so the output pieces start at even sample offsets.  Where the kernel's block grid follows the decimation phase
+// The unit of a context's chunks: lcm(block advance of its filter, 2 D).  Every chunk then produces an even number of outputs
+// whatever the phase (the output pieces start at even sample offsets) and starts on the block grid of the unsplit call.
+static uint64_t mc_chunk_unit(uint32_t taps, uint32_t decim)
+{
+    const uint64_t adv = (uint64_t)if_fir::fft_block_advance((int)taps, (int)decim), two_d = 2ull * decim;
+    return adv / mc_gcd(adv, two_d) * two_d;
+}
+// The effective chunk of a request: the multiple of the unit nearest to it (at least one unit).  Round 3 took the lcm of the
+// REQUEST and 2 D, which multiplied the default 2^24-sample chunk by 11 .. 61 for decimations with a prime factor the request
+// lacked: calls were then never split and the staging slots doubled.
+static uint64_t mc_effective_chunk(uint64_t request, uint32_t taps, uint32_t decim)
+{
+    if (!request)
+        return 0;
+    const uint64_t u = mc_chunk_unit(taps, decim);
+    const uint64_t k = (request + u / 2) / u;
+    return (k ? k : 1) * u;
+}
+
+// Chunk table of a call (`chunk`: the request, rounded by mc_effective_chunk).  Where the kernel's block grid follows the decimation phase
 // the FIRST chunk is n0 samples longer: the chunks behind it then start on phase 0 AND on the block grid of the unsplit
 // call, and no block of a chunk reaches past the chunk's end -- chunked results equal unchunked ones bit for bit at any
 // phase (the input pieces may then start at odd sample offsets, which the overlap-save kernel accepts).
@@ -485,11 +534,7 @@ static void mc_chunks(uint64_t samples, uint64_t chunk, uint64_t consumed, uint3
                       std::vector<McChunk> &out)
 {
     out.clear();
-    if (chunk)
-    {
-        const uint64_t two_d = 2ull * decim;
-        chunk = chunk / mc_gcd(chunk, two_d) * two_d;
-    }
+    chunk = mc_effective_chunk(chunk, taps, decim);
     const uint64_t n0 = (decim - consumed % decim) % decim;
     const uint64_t shift = mc_grid_follows_phase(taps, decim) ? n0 : 0;
     uint64_t done = 0, outs = 0;
@@ -505,12 +550,11 @@ static void mc_chunks(uint64_t samples, uint64_t chunk, uint64_t consumed, uint3
 }
 
 // capacity (samples) of one staging slot of a rank other than 0: the longest chunk a call of `samples` can have
-static uint64_t mc_slot_samples(uint64_t samples, uint64_t chunk, uint32_t decim)
+static uint64_t mc_slot_samples(uint64_t samples, uint64_t chunk, uint32_t decim, uint32_t taps)
 {
     if (!chunk)
         return samples;
-    const uint64_t two_d = 2ull * decim;
-    const uint64_t eff = chunk / mc_gcd(chunk, two_d) * two_d + decim;
+    const uint64_t eff = mc_effective_chunk(chunk, taps, decim) + decim; // (+ the phase shift of an off-phase first chunk)
     return eff < samples ? eff : samples;
 }
 
@@ -589,8 +633,9 @@ IF_FIR_API uint32_t if_fir_mc_debug_plan(uint32_t ulWorld, uint32_t ulChannels, 
 
 #endif // IF_FIR_DEVELOPMENT
 
-// chunk length of the calls that follow: 0 = default (~2^24 samples), otherwise a multiple of 215040 samples (see above);
-// UINT64_MAX = never split.  Every rank must make the same call.
+// chunk length of the calls that follow: 0 = default (~2^24 samples), UINT64_MAX = never split, otherwise a request that is
+// rounded to the nearest multiple of the context's unit (if_fir_mc_get_chunk_samples reports what is used).  Every rank must
+// make the same call.
 IF_FIR_API uint8_t if_fir_mc_set_chunk_samples(if_fir_mc_ctx_t *pCtx, uint64_t ullChunk)
 {
     if (!pCtx)
@@ -599,15 +644,34 @@ IF_FIR_API uint8_t if_fir_mc_set_chunk_samples(if_fir_mc_ctx_t *pCtx, uint64_t u
         pCtx->chunk_samples = 0;
     else if (ullChunk == 0)
         pCtx->chunk_samples = (pCtx->world > 1 || pCtx->loop) ? MC_CHUNK_DEFAULT : 0;
-    else if (ullChunk % MC_CHUNK_UNIT)
-    {
-        mc_err(pCtx, "if_fir_mc_set_chunk_samples: %llu is not a multiple of %llu samples", (unsigned long long)ullChunk,
-               (unsigned long long)MC_CHUNK_UNIT);
-        return 0;
-    }
     else
         pCtx->chunk_samples = ullChunk;
     return 1;
+}
+
+// the chunk in effect (0 = calls are not split) and the unit it is a multiple of
+IF_FIR_API uint8_t if_fir_mc_get_chunk_samples(const if_fir_mc_ctx_t *pCtx, uint64_t *pullChunk, uint64_t *pullUnit)
+{
+    if (!pCtx)
+        return 0;
+    if (pullChunk)
+        *pullChunk = mc_effective_chunk(pCtx->chunk_samples, pCtx->taps, pCtx->decim);
+    if (pullUnit)
+        *pullUnit = mc_chunk_unit(pCtx->taps, pCtx->decim);
+    return 1;
+}
+
+// this rank's status word, formed on the device behind the last filter: 1 if the host saw a filter call fail or if any owned
+// channel's block queue counted an expired wait during this call (the root must not gather incomplete outputs
+// with status 0)
+__global__ void mc_status_kernel(uint32_t *status, const uint32_t *const *faults, uint32_t n, uint32_t host_fail)
+{
+    uint32_t bad = host_fail;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        bad |= (*faults[i] != 0u) ? 1u : 0u;
+    bad = __any(bad) ? 1u : 0u;
+    if (threadIdx.x == 0)
+        status[0] = bad;
 }
 
 IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDevIn, void *const *ppDevOut,
@@ -645,6 +709,22 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
     MC_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<McChunk> chunks;
     mc_chunks(ullSamples, ctx->chunk_samples, ctx->consumed, ctx->decim, ctx->taps, chunks);
+    if (chunks.size() > 1)
+    {
+        // The chunk table (block-grid anchoring, phase shift of the first chunk, sample-aligned piece pointers) is the
+        // overlap-save backend's.  A channel switched to another backend through if_fir_mc_channel_ctx() + if_fir_set_backend()
+        // would be handed pieces its kernels refuse (16-byte alignment) on a grid that is not theirs: refused here,
+        // before anything is posted, on every rank that owns such a channel.  (All ranks run the same configuration.)
+        for (uint32_t c = 0; c < ctx->channels; c++)
+        {
+            if (ctx->fir[c] && if_fir_get_backend(ctx->fir[c]) != IF_FIR_BACKEND_HIP_FFT)
+            {
+                mc_err(ctx, "if_fir_mc_process_device: channel %u is not on the overlap-save backend: calls are split into chunks on "
+                            "that backend only (if_fir_mc_set_chunk_samples(UINT64_MAX) = never split, on every rank)", c);
+                return 0;
+            }
+        }
+    }
     {
         uint64_t longest = 0;
         for (const McChunk &ch : chunks)
@@ -819,8 +899,13 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
         {
             // status word: the protocol above is completed even after a local failure, so that no peer is left waiting;
             // the root learns about it here
-            if (has_staged)
-                MC_STEP(hipMemsetD32Async((hipDeviceptr_t)ctx->d_status, local_fail ? 1 : 0, 1, ctx->xfer_stream));
+            // (the transfer stream is behind the last gather here, which waited for the last filter: the fault counters are final)
+            if (has_staged && he == hipSuccess)
+            {
+                hipLaunchKernelGGL(mc_status_kernel, dim3(1), dim3(64), 0, ctx->xfer_stream, ctx->d_status, ctx->d_faultp, ctx->n_faultp,
+                                   local_fail ? 1u : 0u);
+                he = hipGetLastError();
+            }
             post_group(group);
         }
     }
@@ -831,15 +916,16 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
     auto wait_stream = [&](hipStream_t st) -> hipError_t {
         if (!moving || !ctx->api)
             return hipStreamSynchronize(st);
-        const char *te = getenv("IF_FIR_MC_TIMEOUT_S");
-        const double limit = te && atof(te) > 0 ? atof(te) : 300.0;
+        const double limit = ctx->timeout_s;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; spins++)
         {
             const hipError_t q = hipStreamQuery(st);
+            // (the communicator's error state is looked at once before the first query result is taken: a reported error is
+            // never missed; an idle stream with a clean communicator returns without sleeping)
             if (q != hipErrorNotReady && spins > 0)
                 return q;
-            if ((spins & 63u) == 0u) // (also once before the first query result is taken: a reported error is never missed)
+            if ((spins & 63u) == 0u)
             {
                 ncclResult_t ar = ncclSuccess;
                 if (ctx->api->CommGetAsyncError && ctx->comm &&
@@ -860,6 +946,8 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
                     return hipSuccess;
                 }
             }
+            if (q != hipErrorNotReady)
+                return q; // spin 0: the stream is idle and the communicator clean
             std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
     };
@@ -893,6 +981,14 @@ IF_FIR_API uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *c
     }
     if (local_fail)
         return 0;
+    // the block queue's fault counters of the owned channels (an expired bounded wait must not pass silently
+    // through the multi-channel front either; the streams are idle here, this is one 4-byte read per channel)
+    for (uint32_t c = 0; c < ctx->channels; c++)
+        if (ctx->fir[c] && !if_fir_synchronize(ctx->fir[c]))
+        {
+            mc_err(ctx, "channel %u: %s", c, if_fir_last_error(ctx->fir[c]));
+            return 0;
+        }
     if (root && moving)
     {
         const uint32_t vworld = ctx->loop ? ctx->vranks : ctx->world;

@@ -120,7 +120,7 @@ static int hist_len_for(int T)
         return need;
     if (if_fir::fft_two_partitions(T))
         return 4096; // second partition: 2048 samples of delay + the 2048-sample block overlap
-    const int ovl = 64 * if_fir::fft_overlap_rows(T);
+    const int ovl = 64 * if_fir::fft_overlap_rows(T, 4); // (the longest overlap any decimation of this filter uses)
     return ovl > need ? ovl : need;
 }
 
@@ -513,6 +513,12 @@ static uint8_t check_queue_faults(if_fir_ctx *ctx)
         return 0;
     }
     return 1;
+}
+
+// library-internal (if_fir_mc.cpp): the queue fault counter's device address
+extern "C" __attribute__((visibility("hidden"))) const uint32_t *if_fir_internal_fault_word(const if_fir_ctx_t *pCtx)
+{
+    return pCtx ? reinterpret_cast<const uint32_t *>(static_cast<const char *>(pCtx->d_queue) + 16) : nullptr;
 }
 
 IF_FIR_API uint8_t if_fir_synchronize(if_fir_ctx_t *pCtx)

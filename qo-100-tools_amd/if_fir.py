@@ -28,7 +28,7 @@ EXPORTS = [
     "if_fir_power_device",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
-    "if_fir_mc_set_chunk_samples",
+    "if_fir_mc_set_chunk_samples", "if_fir_mc_get_chunk_samples",
 ]
 # every symbol include/if_fir_debug.h declares: exported by libif_fir_dev.so only
 DEV_EXPORTS = ["if_fir_time_device", "if_fir_debug_stamps", "if_fir_debug_fft_tables", "if_fir_debug_fft_schedule",
@@ -140,6 +140,8 @@ def _load(path, dev):
     L.if_fir_mc_last_error.restype = ctypes.c_char_p
     L.if_fir_mc_set_chunk_samples.argtypes = [vp, u64]
     L.if_fir_mc_set_chunk_samples.restype = u8
+    L.if_fir_mc_get_chunk_samples.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.if_fir_mc_get_chunk_samples.restype = u8
     if dev:
         L.if_fir_time_device.argtypes = [vp, vp, vp, u64, u32, u32, f32p]
         L.if_fir_time_device.restype = u8
@@ -405,6 +407,8 @@ def mc_owner(channel, world):
     return int(lib().if_fir_mc_owner(int(channel), int(world)))
 
 
+# a chunk request the tests use: 215 040 samples (round 3's global unit); the library rounds any request to the context's own
+# unit = lcm(block advance of its filter, 2 D) (IfFirMc.get_chunk_samples)
 MC_CHUNK_UNIT = 215040
 MC_NEVER_SPLIT = (1 << 64) - 1
 
@@ -459,8 +463,14 @@ class IfFirMc:
         self._check(self._L.if_fir_mc_set_input_format(self._ctx, int(fmt)))
 
     def set_chunk_samples(self, chunk):
-        """0 = default chunk, MC_NEVER_SPLIT = whole calls, else a multiple of MC_CHUNK_UNIT samples."""
+        """0 = default chunk, MC_NEVER_SPLIT = whole calls, else a request in samples (rounded to the context's unit)."""
         self._check(self._L.if_fir_mc_set_chunk_samples(self._ctx, int(chunk)))
+
+    def get_chunk_samples(self):
+        """(chunk in effect, 0 = calls are not split; the unit it is a multiple of)"""
+        c, u = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._L.if_fir_mc_get_chunk_samples(self._ctx, ctypes.byref(c), ctypes.byref(u)))
+        return int(c.value), int(u.value)
 
     def channel_ctx(self, channel):
         """Raw if_fir_ctx_t* (int) of a channel this rank owns, else None."""

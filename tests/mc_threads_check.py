@@ -11,7 +11,8 @@ import threading
 
 fake, world, channels = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 mode = sys.argv[4] if len(sys.argv) > 4 else ""
-inject = mode == "inject"       # rank 1's first channel fails its first filter call (development library: test hook)
+qfault = mode == "qfault"       # rank 1's first channel's block queue counts a fault during the first call (development launch 512)
+inject = mode == "inject" or qfault  # rank 1's first channel fails its first filter call (development library: test hook)
 offphase = mode.startswith("offphase")   # "offphase<D>": call lengths that leave the decimation phase != 0
 asyncerr = mode == "asyncerr"   # rank 1's communicator reports an asynchronous error (stand-in transport hook)
 if asyncerr:
@@ -59,7 +60,10 @@ def rank_main(rank):
                 # report it, the others succeed; after a reset on every rank the front works again
                 if rank == 1:
                     h = mc.channel_ctx(1)
-                    assert h and fir.dev_lib().if_fir_set_tuning(h, 4000)
+                    # 4000: the next filter call fails on the host before anything is launched; 1000512 (qfault): the launches
+                    # themselves are accepted, the waves of workgroup 0 count a queue fault and leave their blocks unwritten --
+                    # the failure exists on the DEVICE only and must still reach the owner's return value and the root's
+                    assert h and fir.dev_lib().if_fir_set_tuning(h, 1000000 + 512 if qfault else 4000)
                 barrier.wait()
                 try:
                     mc.process_device([x.data_ptr() for x in ins[0]] if rank == 0 else None,
@@ -68,6 +72,8 @@ def rank_main(rank):
                 except fir.IfFirError as e:
                     injected[rank] = str(e)
                 barrier.wait()
+                if rank == 1 and qfault:
+                    assert fir.dev_lib().if_fir_set_tuning(mc.channel_ctx(1), 0)
                 mc.reset()
                 for k in range(len(calls)):
                     for y in outs[k]:
@@ -123,7 +129,7 @@ if asyncerr:
     sys.exit(0 if good else 1)
 if inject:
     print("injected failure:", injected)
-    ok = ("injected failure" in injected.get(1, "") and "rank 1 reported a filter failure" in injected.get(0, "")
+    ok = (("bounded wait" if qfault else "injected failure") in injected.get(1, "") and "rank 1 reported a filter failure" in injected.get(0, "")
           and all(injected.get(r) == "ok" for r in range(2, world)))
 for c in range(channels):
     with fir.IfFir(taps[c], d, 0) as f:

@@ -508,19 +508,21 @@ def test_multi_channel_front_one_rank(fir, oracle, torch_cuda):
 
 
 def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
-    """The multi-channel front moves and filters a call in chunks (multiples of 215040 samples = lcm of the overlap-save
-    block advances, rounded up to a multiple of twice the decimation) and the contexts keep a whole block overlap of
+    """The multi-channel front moves and filters a call in chunks (multiples of the context's unit = lcm of ITS filter's
+    overlap-save block advance and twice the decimation; a request is rounded to the nearest multiple) and the contexts keep a whole block overlap of
     history, so the blocks of a chunked call start where those of the unsplit call start and see the same samples: ANY
     chunking is bit-identical to no chunking, at ANY decimation phase (round 3: where the block grid follows the phase,
     decimation 4, the first chunk of an off-phase call is that many samples longer, so that no block of a chunk reaches
     past the chunk's end; the pieces then start at odd sample offsets, which the overlap-save kernel accepts).  One rank,
-    three channels, two calls; D = 11 (chunks of 11 x 215040 samples) on a longer stream."""
+    three channels, two calls; D = 11 (round 3: chunks of 11 x 215040 samples; round 4: 5 x 42 240, the multiple of lcm(3840, 22)
+    nearest to the request) on a longer stream; 127 and 65 taps at D = 1, 3, 5 run on 3968-sample blocks (round 4)."""
     torch = torch_cuda
     cases = [(255, 4, 600_000, 1_000_008), (1023, 1, 600_001, 1_000_008), (511, 3, 600_001, 1_000_008),
              (2047, 4, 600_003, 1_000_008), (255, 4, 600_002, 1_000_008), (255, 4, 600_001, 1_000_007),
              (255, 7, 600_003, 1_000_008), (3075, 4, 600_001, 1_000_008), (255, 8, 600_003, 1_000_008), (255, 2, 600_001, 1_000_008), (255, 32, 600_007, 1_000_008),
              (1023, 16, 600_005, 1_000_008), (255, 12, 600_005, 1_000_008), (255, 24, 600_007, 1_000_008), (1023, 40, 600_011, 1_000_008),
              (255, 6, 600_001, 1_000_008), (511, 10, 600_003, 1_000_008),
+             (127, 1, 600_001, 1_000_008), (127, 3, 600_002, 1_000_008), (65, 5, 600_003, 1_000_007), (129, 1, 600_000, 1_000_008),
              (255, 11, 2_500_003, 7_400_000)]
     for t, d, first, n in cases:
         cuts = [0, first, n]
@@ -529,10 +531,15 @@ def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
         dev_in = [torch.from_numpy(oracle.synth_iq(n, 40 + c)).cuda() for c in range(nch)]
         results = {}
         with fir.IfFirMc(taps, d, n) as mc:
-            with pytest.raises(fir.IfFirError, match="multiple"):
-                mc.set_chunk_samples(100_000)
-            for chunk in (fir.MC_NEVER_SPLIT, fir.MC_CHUNK_UNIT, 2 * fir.MC_CHUNK_UNIT, 0):
+            adv = 2048 if t > 3073 else 3968 if (t <= 129 and d % 2) else 3840 if t <= 257 else 3584 if t <= 513 else 3072 if t <= 1025 else 2048
+            for chunk in (fir.MC_NEVER_SPLIT, fir.MC_CHUNK_UNIT, 2 * fir.MC_CHUNK_UNIT, 100_000, 0):
                 mc.set_chunk_samples(chunk)
+                eff, unit = mc.get_chunk_samples()
+                assert unit == np.lcm(adv, 2 * d), (t, d, unit)
+                if chunk in (fir.MC_NEVER_SPLIT, 0):
+                    assert eff == 0                  # one rank moves nothing: its calls are not split unless asked to
+                else:
+                    assert eff % unit == 0 and eff >= unit and (abs(eff - chunk) <= unit // 2 or eff == unit), (t, d, chunk, eff)
                 mc.reset()
                 parts = [[] for _ in range(nch)]
                 for a, b in zip(cuts[:-1], cuts[1:]):
@@ -552,6 +559,93 @@ def test_multi_channel_front_chunked_equals_unchunked(fir, oracle, torch_cuda):
                 assert np.array_equal(res[c], ref[c]), (t, d, first, chunk, c)
         l2, mx = oracle.err_metrics(ref[nch - 1], oracle.fir_f64(taps[nch - 1], dev_in[nch - 1].cpu().numpy(), d))
         assert l2 <= TOL and mx <= TOL, (t, d, l2, mx)
+
+
+def test_multi_channel_front_splits_calls_on_the_overlap_save_backend_only(fir, oracle, torch_cuda):
+    """the chunk table (block grid, phase shift of the first chunk, sample-aligned pieces) is the overlap-save
+    backend's.  A channel switched to another backend is refused when the call would be split -- before anything runs --
+    and works unsplit."""
+    torch = torch_cuda
+    t, d, n = 255, 4, 700_001
+    taps = np.stack([fir.bpf_design(t, 0.15, 0.25), fir.bpf_design(t, 0.02, 0.08)])
+    dev_in = [torch.from_numpy(oracle.synth_iq(n, 60 + c)).cuda() for c in range(2)]
+    for fmt in (fir.INPUT_F32, fir.INPUT_I16):
+        with fir.IfFirMc(taps, d, n) as mc:
+            if fmt == fir.INPUT_I16:
+                mc.set_input_format(fmt)
+                src = [torch.from_numpy(np.random.default_rng(c).integers(-3000, 3000, 2 * n, dtype=np.int16)).cuda() for c in range(2)]
+            else:
+                src = dev_in
+            mc.set_backend(fir.BACKEND_HIP_GENERIC)
+            mc.set_chunk_samples(fir.MC_CHUNK_UNIT)
+            m = oracle.out_count(0, n, d)
+            outs = [torch.zeros(2 * m, dtype=torch.float32, device="cuda") for _ in range(2)]
+            # an off-phase stream position first (one unsplit call of 3 samples), then a call that would be split
+            mc.set_chunk_samples(fir.MC_NEVER_SPLIT)
+            assert mc.process_device([x.data_ptr() for x in src], [o.data_ptr() for o in outs], 3) == 1
+            mc.set_chunk_samples(fir.MC_CHUNK_UNIT)
+            with pytest.raises(fir.IfFirError, match="overlap-save backend"):
+                mc.process_device([x.data_ptr() for x in src], [o.data_ptr() for o in outs], n)
+            mc.set_chunk_samples(fir.MC_NEVER_SPLIT)
+            mc.reset()
+            assert mc.process_device([x.data_ptr() for x in src], [o.data_ptr() for o in outs], n) == m
+            xin = src[1].cpu().numpy()
+            xin = xin.astype(np.float32) * np.float32(2.0 ** -15) if fmt == fir.INPUT_I16 else xin
+            l2, mx = oracle.err_metrics(outs[1].cpu().numpy(), oracle.fir_f64(taps[1], xin, d))
+            assert l2 <= TOL and mx <= TOL, (fmt, l2, mx)
+
+
+@pytest.mark.parametrize("t,d", [(127, 1), (129, 1), (65, 3), (3, 1), (127, 5), (97, 7), (1, 1)])
+def test_short_filters_on_two_overlap_rows(fir, oracle, t, d):
+    """Round 4 (VERDICT r3 #1a): filters of at most 129 taps on the full-rate pipeline (D = 1, odd D) discard 2 rows of a
+    4096-point block instead of 4 (L = 3968).  Against the float64 oracle: one call, ragged pieces around the new block
+    advance, float32 / int16 input, the NCO; bit-identical on a one-workgroup grid; and within tolerance of the 4-row kernel
+    (development variant 1024), which has a different block grid."""
+    rng = np.random.default_rng(1000 * t + d)
+    taps = fir.bpf_design(t) if (t % 2 and t >= 3) else np.array([0.75], dtype=np.float32)
+    n = 3968 * 9 + 17
+    x = np.concatenate([oracle.synth_iq(n // 2, 5), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
+    ref = oracle.fir_f64(taps, x, d)
+    with fir.IfFir(taps, d, n, dev=True) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        y = f.process(x)
+        l2, mx = oracle.err_metrics(y, ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        f.reset()
+        cuts = [0, 1, 127, 128, 129, 3967, 3968, 3969, 2 * 3968, 2 * 3968 + 3840, 30_000, n]
+        parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        # cuts at multiples of the block advance (and of D): bit-identical to the unsplit call
+        f.reset()
+        cuts = [0, 3968 * d, 4 * 3968 * d if 4 * 3968 * d < n else n, n]
+        parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        assert np.array_equal(np.concatenate(parts), y)
+        f.reset()
+        f.set_tuning(2001)                   # one workgroup: every block through the queue
+        assert np.array_equal(f.process(x), y)
+        os.environ["IF_FIR_DEBUG"] = "1"
+        try:
+            f.reset()
+            f.set_tuning(1000000 + 1024)     # the 4-row kernel: other block grid, same filter
+            y4 = f.process(x)
+        finally:
+            os.environ.pop("IF_FIR_DEBUG", None)
+        f.set_tuning(0)
+        l2, mx = oracle.err_metrics(y4, ref)
+        assert l2 <= TOL and mx <= TOL, ("4 rows", l2, mx)
+        # NCO and int16 input through the same instantiations
+        f.reset()
+        f.set_nco(0.1234)
+        yn = f.process(x)
+        l2, mx = oracle.err_metrics(yn, oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(0.1234)))
+        assert l2 <= TOL and mx <= TOL, ("nco", l2, mx)
+    xi = rng.integers(-32768, 32768, 2 * n, dtype=np.int16)
+    with fir.IfFir(taps, d, n) as f:
+        f.set_input_format(fir.INPUT_I16)
+        yi = f.process(xi)
+        l2, mx = oracle.err_metrics(yi, oracle.fir_f64(taps, xi.astype(np.float32) * np.float32(2.0 ** -15), d))
+        assert l2 <= TOL and mx <= TOL, ("i16", l2, mx)
 
 
 def test_multi_channel_front_loopback_over_the_real_rccl(fir, oracle, torch_cuda):

@@ -273,7 +273,8 @@ def test_no_overlap_save_instantiation_spills():
     # and 8 / 16 with and without NCO) variants + 8 accumulating ones
     # + 20 + 20 (round 3): the decimate-by-4 / -by-2 tails keeping every sub-th output (decimation 8, 12, ..., 64 / 6, 10, ..., 62)
     # + 16: the second partition of 3074..4096-tap filters behind the four single-channel tails (accumulating store, 32 rows)
-    assert len(fft) == 194, len(fft)
+    # + 8 (round 4): the full-rate pipeline with 2 overlap rows (<= 129 taps; D = 1 and the selecting store)
+    assert len(fft) == 202, len(fft)
     for name, res in fft.items():
         assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
 

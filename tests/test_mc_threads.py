@@ -48,6 +48,17 @@ def test_remote_filter_failure_reaches_the_root_and_nobody_hangs(fake_rccl):
     assert "injected failure" in run.stdout and "bit-identical" in run.stdout
 
 
+def test_remote_block_queue_fault_reaches_the_root(fake_rccl):
+    """an expired bounded wait of the overlap-save kernel's block queue leaves blocks unwritten and exists on the
+    device only (a counter).  Through the multi-channel front it must still fail the call on the owner (its fault counters
+    are read after the final waits) AND on the root (the owner's status word is formed on the device behind its last filter,
+    from those counters) -- not gather incomplete outputs with status 0.  Development launch 512 on rank 1's channel."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mc_threads_check.py"), fake_rccl, "3", "5", "qfault"],
+                         capture_output=True, text=True, timeout=400)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert "bounded wait" in run.stdout and "rank 1 reported a filter failure" in run.stdout and "bit-identical" in run.stdout
+
+
 def test_asynchronous_rccl_error_is_reported_not_waited_for(fake_rccl):
     """the final waits of if_fir_mc_process_device poll ncclCommGetAsyncError instead of blocking.  The stand-in
     transport makes rank 1's communicator report an error: that rank fails the call with the message, aborts its communicator
