@@ -295,6 +295,52 @@ def dry_run(args, rank, world, json_fd):
         dist.destroy_process_group()
 
 
+MULTI_GPU_CHECK_KEYS = ("world", "channels", "samples_per_channel", "taps", "decimation", "transport", "calls", "per_rank_ms",
+                        "end_to_end_ms", "end_to_end_msamples_per_s", "bytes_sent_per_rank", "bytes_received_per_rank",
+                        "bytes_through_send_recv", "channels_identical", "ok")
+
+
+def mc_transfer_bytes(world, channels, samples, outputs, in_bytes=8):
+    """Bytes every rank hands to ncclSend / takes from ncclRecv in ONE call of the multi-channel front (if_fir_mc.cpp's
+    plan): channel c != 0 mod world travels root -> owner (samples x in_bytes) and its outputs back (outputs x 8); every
+    owner other than the root sends a 4-byte status word."""
+    sent, recv = [0] * world, [0] * world
+    for c in range(channels):
+        o = c % world
+        if o == 0:
+            continue
+        sent[0] += samples * in_bytes
+        recv[o] += samples * in_bytes
+        sent[o] += outputs * 8
+        recv[0] += outputs * 8
+    for r in range(1, min(world, channels)):
+        sent[r] += 4
+        recv[0] += 4
+    return sent, recv
+
+
+def multi_gpu_check_record(world, channels, samples, taps, decimation, transport, per_rank_ms_calls, identical, in_bytes=8,
+                           outputs=None):
+    """The record a multi-GPU box must produce in one go: per-rank wall times of every call of the multi-channel
+    front, the bytes that went through ncclSend / ncclRecv, and per channel whether rank 0 found it bit-identical to a
+    single-channel context.  Printed by `bench.py --gpus N --channels C --scatter-mc` (extra.scatter_gather_mc.multi_gpu_check),
+    by its --dry-run rehearsal over gloo, and by tools/mc_selfcheck.py (one JSON line)."""
+    if outputs is None:   # (a stream position on the decimation grid; off-phase callers pass their count)
+        outputs = (samples + decimation - 1) // decimation
+    sent, recv = mc_transfer_bytes(world, channels, samples, outputs, in_bytes)
+    best = min(max(call) for call in per_rank_ms_calls) if per_rank_ms_calls else None
+    rec = {"world": world, "channels": channels, "samples_per_channel": samples, "taps": taps, "decimation": decimation,
+           "transport": transport, "calls": len(per_rank_ms_calls),
+           "per_rank_ms": [[round(v, 4) for v in call] for call in per_rank_ms_calls],
+           "end_to_end_ms": round(best, 4) if best is not None else None,
+           "end_to_end_msamples_per_s": round(channels * samples / (best * 1e-3) / 1e6, 1) if best else None,
+           "bytes_sent_per_rank": sent, "bytes_received_per_rank": recv, "bytes_through_send_recv": sum(sent),
+           "channels_identical": identical,
+           "ok": bool(identical) and all(v is True for v in identical)}
+    assert tuple(rec) == MULTI_GPU_CHECK_KEYS
+    return rec
+
+
 def dry_run_scatter(rank, world, decim):
     """--dry-run --scatter: the control flow of the real --scatter leg (channel_shard.scatter_channels -> per-channel
     filter -> gather_outputs, barriers in the same places) on CPU tensors over gloo; the filter is a stand-in that keeps
@@ -353,6 +399,7 @@ def dry_run_scatter_mc(rank, world, taps_n, decim):
     # every rank walks the same group numbers (a rank without operations in a group skips it)
     gmax = torch.tensor([last_group], dtype=torch.int64)
     dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+    t_walk = time.perf_counter()
     for g in range(int(gmax.item()) + 1):
         ops, after = [], []
         for o in groups.get(g, []):
@@ -385,8 +432,23 @@ def dry_run_scatter_mc(rank, world, taps_n, decim):
                 continue
             ok = ok and bool(torch.equal(outs[c], pattern(c)[n0::decim]))
         ok = ok and bool((status == 0).all())
+    # the record of the real leg, filled from this rehearsal: per-rank times of the walk above, bytes from the plan itself
+    t_all = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(t_all, torch.tensor([(time.perf_counter() - t_walk) * 1e3], dtype=torch.float64))
+    identical = None
+    if root:
+        identical = [True if c % world == 0 else bool(torch.equal(outs[c], pattern(c)[n0::decim])) for c in range(channels)]
+    check = multi_gpu_check_record(world, channels, samples, taps_n, decim, "gloo (dry run: the plan's operations as batch_isend_irecv)",
+                                   [[float(t[0]) for t in t_all]], identical, outputs=m_total)
+    sent = sum(o["bytes"] for o in plan if o["kind"] == 0)
+    recv = sum(o["bytes"] for o in plan if o["kind"] == 1)
+    # (the plan of THIS rank must move exactly the bytes the record's formula states for it)
+    plan_agrees = sent == check["bytes_sent_per_rank"][rank] and recv == check["bytes_received_per_rank"][rank]
+    agree = torch.tensor([1 if plan_agrees else 0], dtype=torch.int32)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
     return {"dry_run": True, "world": world, "channels": channels, "chunks": len({o["chunk"] for o in plan if o["phase"] == 0}),
-            "groups": int(gmax.item()) + 1, "ok": ok,
+            "groups": int(gmax.item()) + 1, "ok": ok, "plan_bytes_agree_with_record": bool(agree.item()),
+            "multi_gpu_check": check,
             "note": "if_fir_mc_debug_plan executed group by group over gloo with two-slot staging and a stand-in filter"}
 
 
@@ -768,33 +830,46 @@ def main():
         if rank == 0:
             idt = torch.frombuffer(bytearray(fir.mc_unique_id()), dtype=torch.uint8).to(dev)
         dist.broadcast(idt, 0)
-        taps_all = np.stack([taps] * world)
+        # BASELINE configs[3] in one call: all `total_channels` channels resident on rank 0, channel c filtered by rank c mod world
+        mc_channels = total_channels
+        taps_all = np.stack([taps] * mc_channels)
         with fir.IfFirMc(taps_all, decim, n, device=local_rank, rank=rank, world=world,
                          unique_id=bytes(idt.cpu().numpy().tobytes())) as mc:
             ins = outs_mc = None
             if rank == 0:
-                ins = [x] + [torch.empty_like(x) for _ in range(world - 1)]
-                for c in range(1, world):
+                ins = [x] + [torch.empty_like(x) for _ in range(mc_channels - 1)]
+                for c in range(1, mc_channels):
                     f.synth_device(ins[c].data_ptr(), 0, n, c)
-                outs_mc = [torch.empty(2 * m, dtype=torch.float32, device=dev) for _ in range(world)]
+                outs_mc = [torch.empty(2 * m, dtype=torch.float32, device=dev) for _ in range(mc_channels)]
                 torch.cuda.synchronize()
-            times = []
+            times, per_rank = [], []
             for _ in range(3):
                 mc.reset()
                 dist.barrier()
                 ts = time.perf_counter()
                 mc.process_device([t_.data_ptr() for t_ in ins] if rank == 0 else None,
                                   [t_.data_ptr() for t_ in outs_mc] if rank == 0 else None, n)
+                mine_ms = (time.perf_counter() - ts) * 1e3
                 dist.barrier()
                 times.append(time.perf_counter() - ts)
-            check = None
+                t_all = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+                dist.all_gather(t_all, torch.tensor([mine_ms], dtype=torch.float64, device=dev))
+                per_rank.append([float(t_[0]) for t_ in t_all])
+            identical = None
             if rank == 0:
+                # every channel against a single-channel context fed the same (first) call
+                identical = []
+                for c in range(mc_channels):
+                    f.reset()
+                    f.process_device(ins[c].data_ptr(), y.data_ptr(), n)
+                    torch.cuda.synchronize()
+                    identical.append(bool(torch.equal(y, outs_mc[c])))
                 f.reset()
-                f.process_device(x.data_ptr(), y.data_ptr(), n)
-                torch.cuda.synchronize()
-                check = bool(torch.equal(y, outs_mc[0]))
-            extra["scatter_gather_mc"] = {"end_to_end_s": min(times), "end_to_end_msamples_per_s": world * n / min(times) / 1e6,
-                                          "channel0_identical_to_single_context": check,
+            extra["scatter_gather_mc"] = {"end_to_end_s": min(times), "end_to_end_msamples_per_s": mc_channels * n / min(times) / 1e6,
+                                          "channel0_identical_to_single_context": identical[0] if identical else None,
+                                          "multi_gpu_check": multi_gpu_check_record(world, mc_channels, n, taps_n, decim,
+                                                                                    "rccl (ncclSend/ncclRecv inside libif_fir.so)",
+                                                                                    per_rank, identical),
                                           "note": "if_fir_mc_process_device: grouped RCCL send/recv from rank 0 inside libif_fir.so"}
 
     if rank == 0:

@@ -198,7 +198,7 @@ uint8_t if_fir_mc_process_device(if_fir_mc_ctx_t *pCtx, const void *const *ppDev
                                  uint64_t ullSamples, uint64_t *pullOutSamples);
 /* chunk length of the following calls: 0 = default (about 2^24 samples; with one rank: never split), UINT64_MAX = never split,
  * otherwise a request in samples.  The library rounds the request to the nearest multiple of the context's UNIT = lcm(block
- * advance of the filter's overlap-save kernel -- 3968, 3840, 3584, 3072, 2048 or 1024 samples --, twice the decimation) and,
+ * advance of the filter's overlap-save kernel -- 3840, 3584, 3072, 2048 or 1024 samples --, twice the decimation) and,
  * where the kernel's block grid follows the decimation phase (every even decimation), makes the first chunk of an off-phase call
  * that many samples longer: the blocks of a chunked call are then the blocks of an unchunked one and the results are
  * bit-identical whatever the chunk and whatever the phase.  Calls are split on the overlap-save backend (AUTO's pick) only: with a

@@ -13,8 +13,8 @@
  *                  8 / 128 cache-line touches ahead of the next block group, ...  (DESIGN.md §3.4); 256 no tail phase in
  *                  short launches; 512 the waves of workgroup 0 count a queue fault and leave as if their bounded wait had
  *                  expired: blocks stay unwritten and if_fir_synchronize must report it (the fault path's test);
- *                  1024 (round 4) filters of at most 129 taps on the 4-row kernel as before round 4 (same results to tolerance;
- *                  A/B timing against the 2-row kernel); 2048 the queue's tail phase in launches of up to 16 two-wave rounds
+ *                  1024 (round 4) filters of at most 129 taps on the full-rate pipeline with 2 overlap rows (L = 3968) instead of 4
+ *                  (same results to tolerance; measured 3 % slower on BASELINE configs[1]); 2048 the queue's tail phase in launches of up to 16 two-wave rounds
  *   3000           decimation 2, 6, 10, ..., 62 through the full-rate kernel + selecting store instead of the decimate-by-2 tail (same results to
  *                  tolerance; A/B timing)
  *   4000           the next call fails before anything is launched (IF_FIR_DEBUG=1): lets tests reach callers' error paths

@@ -134,6 +134,78 @@ __device__ __forceinline__ void fft16(cf (&v)[16])
     bfly4<INV>(y[3][0], y[3][1], y[3][2], y[3][3], v[3], v[7], v[11], v[15]);
 }
 
+// ---- twiddles in (cos, tan) form (round 4) ---------------------------------------------------------------------------------
+// A twiddle w = c (1 + j t) is kept as the pair E = (c, t).  x (1 + j t) is ONE packed FMA and a +- c u another, so a radix-4
+// butterfly whose inputs 1..3 carry twiddles w1, w2, w3 is 11 packed FMAs (3 twiddle multiplies + 8 adds = 14 instructions in the
+// usual form); the third entry of a butterfly holds (c3 / c1, t3):
+//   u2 = x2 (1 + j t2);  t0 = x0 + c2 u2;  t1 = x0 - c2 u2;  u1, u3 likewise;  v+- = u1 +- (c3 / c1) u3;
+//   X0 = t0 + c1 v+;  X2 = t0 - c1 v+;  X1 = t1 -+ j c1 v-;  X3 = t1 +- j c1 v-
+// A 16-point transform whose input j carries b^j (b = the lane's base twiddle: the twiddle a three-pass transform applies
+// between two passes, moved from the outputs of one pass to the inputs of the next) is 8 such butterflies = 88 packed
+// instructions where transform + 15 twiddle multiplies were 110.  An exact zero of a cosine is stored as 2^-30 (host,
+// tan_entry): the tangent stays finite and the products are exact to rounding.  Measured (tools/ubench_energy.hip,
+// profiles/r04_energy_per_instruction.txt): a packed FMA costs 1.18 x the energy of a packed add; the group as a whole -4.5 %.
+template <bool INV>
+__device__ __forceinline__ cf tw_u(cf x, cf e) // x (1 + j t) (forward) / x (1 - j t) (inverse: conjugate twiddles)
+{
+    cf d;
+    if (INV)
+        asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(e));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(x), "v"(e));
+    return d;
+}
+template <bool NEG>
+__device__ __forceinline__ cf tw_ac(cf a, cf u, cf e) // a +- e.x u
+{
+    cf d;
+    if (NEG)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(u), "v"(e), "v"(a));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(u), "v"(e), "v"(a));
+    return d;
+}
+template <bool PLUSJ>
+__device__ __forceinline__ cf tw_ajc(cf a, cf u, cf e) // a +- j e.x u
+{
+    cf d;
+    if (PLUSJ) // (a.x - c u.y, a.y + c u.x)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(u), "v"(e), "v"(a));
+    else       // (a.x + c u.y, a.y - c u.x)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(u), "v"(e), "v"(a));
+    return d;
+}
+template <bool INV>
+__device__ __forceinline__ void bfly4_tw(cf x0, cf x1, cf x2, cf x3, cf e1, cf e2, cf e3, cf &X0, cf &X1, cf &X2, cf &X3)
+{
+    const cf u2 = tw_u<INV>(x2, e2);
+    const cf t0 = tw_ac<false>(x0, u2, e2), t1 = tw_ac<true>(x0, u2, e2);
+    const cf u1 = tw_u<INV>(x1, e1), u3 = tw_u<INV>(x3, e3);
+    const cf vp = tw_ac<false>(u1, u3, e3), vm = tw_ac<true>(u1, u3, e3); // e3.x = c3 / c1
+    X0 = tw_ac<false>(t0, vp, e1);
+    X2 = tw_ac<true>(t0, vp, e1);
+    X1 = tw_ajc<INV>(t1, vm, e1); // forward: t1 - j c1 v-
+    X3 = tw_ajc<!INV>(t1, vm, e1);
+}
+// 16-point transform of v[j] b^j (inverse: v[j] conj(b)^j), natural order in and out.  Table (host, tan_fft16_entries): entries
+// 0..2 = b^4, b^8, b^12 (first radix-4 stage; its outputs still owe b^i); entries 3 + 3 q + (i - 1) = b^i W16^(i q), i = 1..3 (the
+// owed factor merged with the transform's own twiddle); entry k at e[k * STRIDE].
+template <bool INV, int STRIDE>
+__device__ __forceinline__ void fft16_tw(cf (&v)[16], const f2v *e)
+{
+    cf y[4][4];
+    {
+        const cf e1 = e[0], e2 = e[STRIDE], e3 = e[2 * STRIDE];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            bfly4_tw<INV>(v[i], v[i + 4], v[i + 8], v[i + 12], e1, e2, e3, y[0][i], y[1][i], y[2][i], y[3][i]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        bfly4_tw<INV>(y[q][0], y[q][1], y[q][2], y[q][3], e[(3 + 3 * q) * STRIDE], e[(4 + 3 * q) * STRIDE], e[(5 + 3 * q) * STRIDE],
+                      v[q], v[q + 4], v[q + 8], v[q + 12]);
+}
+
 __device__ __forceinline__ void swap32(cf &vdst, cf &src)
 {
     u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(vdst.x), __float_as_uint(src.x), false, false);
@@ -169,6 +241,24 @@ static_assert(FFT_WAVES == (int)QB, "one slot of a block group per wave of the w
 constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_TWD = 65536 + 2048, LDS_TWE = LDS_TWD + 8192,
               LDS_NCO = LDS_TWE + 8192, LDS_TWF = LDS_NCO + 512, LDS_XB = LDS_TWF + 2048;
 static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
+// Image of the decimate-by-4 kernels (round 4, twiddles in (cos, tan) form; same size, other contents -- fft_build_tables):
+//   LDS_TW1: pass 3, first stage   [(i*3 + e)*64 + lane]   b = W4096^(k0 + 16 k1), k0 = 4 (lane/16) + i, k1 = lane%16
+//   LDS_TW2: pass 2                [(i*15 + e)*4 + lane/16] b = W256^k0
+//   LDS_TWD: inverse, last pass    [e*64 + lane]            b = W1024^lane
+//   LDS_TWE: inverse, middle pass  [e*4 + lane%4]           b = W64^(lane%4)
+//   LDS_HP : G'[m0][q] = b^m0 G[m0][q] (the factor pass 3's first stage still owes, merged into the table)
+// overlap rows of filters of at most 129 taps on the full-rate pipeline: 4 (L = 3840, as for <= 257 taps) or 2 (L = 3968).
+// Round 4 built the 2-row kernel for BASELINE configs[1] and MEASURED it 3 % slower than the 4-row one there
+// (profiles/r04_two_row_overlap.txt), so 4 stays the default; development variant 1024 runs the other one.
+#ifndef IF_FIR_FFT_SHORT_ROWS
+#define IF_FIR_FFT_SHORT_ROWS 4
+#endif
+#ifndef IF_FIR_FFT_EDGE_MIN
+#define IF_FIR_FFT_EDGE_MIN 0 // (A/B builds: at least this many first / last rows of a block keep the default cache policy)
+#endif
+#ifndef IF_FIR_FFT_TAN
+#define IF_FIR_FFT_TAN 1 // 0: the decimate-by-4 kernels in round 3's form (A/B builds)
+#endif
 constexpr int LDS_Q = LDS_XB + FFT_WAVES * XBUF; // workgroup block queue: slot counter (16 B) + ring of group entries
 constexpr int LDS_QPTR = LDS_Q + 16 + Q_RING * 8; // 16-slot bank: the 16 output pointers (kept out of the SGPRs)
 constexpr int LDS_QNCO = LDS_QPTR + 16 * 8; // bank tails with an NCO: the block's rotation phasor, one 8-byte word per wave
@@ -507,6 +597,41 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
     inverse_tail256(a, c, twe, xb, lane);
 }
 
+// the same with the twiddles in (cos, tan) form on the inputs of the two 16-point transforms (round 4; tables tb = LDS_TWE,
+// tc = LDS_TWD): 4-point inverse over k2' (plain) -> X -> iFFT16 over k1, inputs carry conj(W64^mu2)^k1 -> Y -> iFFT16 over k0,
+// inputs carry conj(W1024^lane)^k0.  208 packed instructions where inverse_dec4 has 246.
+__device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16], const f2v *tb, const f2v *tc, char *xb, int lane)
+{
+    cf a[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        bfly4<true>(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3], a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+    const int g = lane >> 4, m = lane & 15;
+    {
+        char *wr = xb + g * XREG + m * 8;
+        const char *rd = xb + g * XREG + m * XROW;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            a[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+    }
+    fft16_tw<true, 4>(a, tb + (lane & 3)); // over k1 -> mu1
+    {
+        const int k0 = 4 * g + (m >> 2), low = m & 3;
+        char *wr = xb + low * XREG + k0 * 8;
+        const char *rd = xb + (lane & 3) * XREG + (lane >> 2) * XROW;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            c[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+    }
+    fft16_tw<true, 64>(c, tc + lane); // over k0 -> mu0
+}
+
 #ifdef IF_FIR_FFT_ROWS // ================= kernel + launcher: the per-overlap-length compilation units =================
 template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, int CHAN, bool DECN, bool ACC>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
@@ -534,6 +659,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // fs/F-rate block (OVL_ROWS / 4, / 2, ...), which 128 samples are not
     static_assert(OVL_ROWS >= 4 || (!DEC4 && !ACC), "2 overlap rows: full-rate pipeline (D = 1, odd D) only");
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
+    // decimate-by-4 kernels (single channel incl. the multiples of 4, and the bank at decimation 4): twiddles in (cos, tan) form
+    // on the inputs of passes 2 and 3 and of the small inverse (round 4); every other tail keeps round 3's form and tables
+    constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4);
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
     const char *in = reinterpret_cast<const char *>(in_);
@@ -570,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             for (int rho = 0; rho < 4; rho++)
 #pragma unroll
                 for (int j = 0; j < 16; j++)
-                    load_row<I16, LAUX, OVL_ROWS>(r, srd, lane, 4 * j + rho);
+                    load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, srd, lane, 4 * j + rho);
             loaded = true;
         }
     }
@@ -707,7 +835,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int rho = 0; rho < 4; rho++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX, OVL_ROWS>(r, srd, lane, 4 * j + rho);
+                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, srd, lane, 4 * j + rho);
             }
             else
             {
@@ -745,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
             for (int j = 0; j < 16; j++)
             {
-                if (j == 0)
+                if (j == 0 || TAN) // (TAN: the twiddle W4096^((lane + 64 rho) k0) is applied on the inputs of passes 2 and 3)
                     r[4 * j + rho] = t[j];
                 else
                 {
@@ -769,6 +897,17 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
             for (int j = 0; j < 16; j++)
                 t[j] = r[phys(i, j)];
+            if constexpr (TAN)
+            {
+                // inputs carry W256^(n1 k0), k0 = 4 (lane / 16) + i: the part of pass 1's twiddle that depends on n1; the rest,
+                // W4096^(n2 k0), joins this pass's own W256^(n2 k1) on the inputs of pass 3
+                fft16_tw<false, 4>(t, tw2 + i * 60 + (lane >> 4));
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    r[phys(i, j)] = t[j];
+            }
+            else
+            {
             fft16<false>(t);
 #pragma unroll
             for (int j = 0; j < 16; j++)
@@ -784,6 +923,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #endif
                     r[phys(i, j)] = cmul_v<false>(t[j], w);
                 }
+            }
             }
         }
         FFT_STAMP(3);
@@ -863,7 +1003,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int q = 0; q < 4; q++)
-                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, 4 * b + q));
+                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, 4 * b + q));
                 }
                 if (wanted)
                 {
@@ -900,7 +1040,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int q = 0; q < 4; q++)
-                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, 4 * b + q));
+                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, 4 * b + q));
                 }
             }
         }
@@ -927,7 +1067,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 8; j < 16; j++)
-                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
                 }
             }
             // 2048-point inverse as TWO 1024-point inverses (even and odd outputs), so that every lane ends up with two
@@ -1032,7 +1172,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 8; j++)
-                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
             }
             unsigned vo128 = (unsigned)lane * 16u;
             if constexpr (CHAN == 2)
@@ -1120,7 +1260,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     {
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
                     }
                 }
                 cf c[16];
@@ -1131,7 +1271,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
                 }
                 // mix-down: exp(-j 2 pi s a / 16), a = abs0 + n0 + 8 m: the call constant rot0 times (-1)^(s m); m = obase +
                 // 32 (mu0 - first) + 2 mu1 + mu2 with obase even, so the sign is (-1)^(s mu2)
@@ -1177,10 +1317,22 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     t[j] = r[phys(i, j)];
+                if constexpr (TAN)
+                {
+                    // inputs carry b^n2, b = W4096^(k0 + 16 k1); the b^m0 this stage still owes sits in the table G'
+                    const cf e1 = tw1[(i * 3 + 0) * 64 + lane], e2 = tw1[(i * 3 + 1) * 64 + lane], e3 = tw1[(i * 3 + 2) * 64 + lane];
+#pragma unroll
+                    for (int m0 = 0; m0 < 4; m0++)
+                        bfly4_tw<false>(t[m0], t[m0 + 4], t[m0 + 8], t[m0 + 12], e1, e2, e3, r[phys(i, m0)], r[phys(i, m0 + 4)],
+                                        r[phys(i, m0 + 8)], r[phys(i, m0 + 12)]);
+                }
+                else
+                {
 #pragma unroll
                 for (int m0 = 0; m0 < 4; m0++)
                     bfly4<false>(t[m0], t[m0 + 4], t[m0 + 8], t[m0 + 12], r[phys(i, m0)], r[phys(i, m0 + 4)],
                                  r[phys(i, m0 + 8)], r[phys(i, m0 + 12)]);
+                }
             }
             constexpr int MU0_FIRST = OVL_ROWS / 4;
             const int nch = (int)chan.count;
@@ -1208,18 +1360,21 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     {
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
                     }
                 }
                 cf c[16];
-                inverse_dec4(z, c, twd, twe, xb, lane);
+                if constexpr (TAN)
+                    inverse_dec4_tan(z, c, twe, twd, xb, lane);
+                else
+                    inverse_dec4(z, c, twd, twe, xb, lane);
                 if (last && next_fast)
                 {
 #pragma unroll
                     for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
                 }
                 // mix-down of the decimated output: exp(-j 2 pi slot a / 16), a = abs0 + n0 + 4 m, m = obase + 64 r + lane
                 // with obase a multiple of 4: a call constant (rot0, host) times a quarter turn per lane
@@ -1249,9 +1404,21 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 //   G[m0][q] = W16^(m0 q) * sum_p H(q + 4p) W4^(m0 p)      (host table, fft_build_tables)
                 // i.e. 16 complex MACs instead of 4 butterflies + 8 twiddles + 16 multiplies + 12 adds.
                 cf y[4][4];
+                if constexpr (TAN)
+                {
+                    // (cos, tan) form: the inputs carry b^n2, b = W4096^(k0 + 16 k1) (pass 1's and pass 2's twiddles, moved here);
+                    // this stage applies b^4, b^8, b^12 inside its butterflies, the b^m0 it still owes sits in the table (G')
+                    const cf e1 = tw1[(i * 3 + 0) * 64 + lane], e2 = tw1[(i * 3 + 1) * 64 + lane], e3 = tw1[(i * 3 + 2) * 64 + lane];
+#pragma unroll
+                    for (int m0 = 0; m0 < 4; m0++)
+                        bfly4_tw<false>(t[m0], t[m0 + 4], t[m0 + 8], t[m0 + 12], e1, e2, e3, y[0][m0], y[1][m0], y[2][m0], y[3][m0]);
+                }
+                else
+                {
 #pragma unroll
                 for (int m0 = 0; m0 < 4; m0++)
                     bfly4<false>(t[m0], t[m0 + 4], t[m0 + 8], t[m0 + 12], y[0][m0], y[1][m0], y[2][m0], y[3][m0]);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++)
                 {
@@ -1268,12 +1435,15 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
                 }
                 }
             FFT_STAMP(5);
             cf c[16];
-            inverse_dec4(z, c, twd, twe, xb, lane);
+            if constexpr (TAN)
+                inverse_dec4_tan(z, c, twe, twd, xb, lane);
+            else
+                inverse_dec4(z, c, twd, twe, xb, lane);
             FFT_STAMP(6);
             if (next_fast)
             {
@@ -1281,7 +1451,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
             }
             constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
             if constexpr (NCO)
@@ -1436,7 +1606,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX, OVL_ROWS>(r, nsrd, lane, 4 * j + rho);
+                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, 4 * j + rho);
                 }
                 }
         }
@@ -1576,15 +1746,15 @@ bool fft_two_partitions(int T)
     return T > 3073;
 }
 
-// Overlap rows of the (taps, decimation) pair.  Round 4: filters of at most 129 taps on the full-rate pipeline (D = 1 and the odd
-// decimations, which run it with a selecting store) discard 2 rows only: L = 3968.  2^26 samples are then 16 913 blocks = 8
-// two-wave rounds of the 2048 waves + a tail-phase round (with 4 rows: 17 477 blocks = 8.53 per wave, and the waves with 8 blocks
-// waited for those with 9: 12 % of that launch, DESIGN.md §3.4 finding 11).
+// Overlap rows of the (taps, decimation) pair.  Round 4 built a 2-row kernel (L = 3968) for filters of at most 129 taps on the
+// full-rate pipeline (D = 1 and the odd decimations): 2^26 samples are then 16 913 blocks instead of 17 477.  Measured on BASELINE
+// configs[1] it is 3 % SLOWER than the 4-row kernel (profiles/r04_two_row_overlap.txt), so the default stays 4 rows
+// (IF_FIR_FFT_SHORT_ROWS) and the 2-row unit is a development variant.
 int fft_overlap_rows(int T, int D)
 {
     if (fft_two_partitions(T))
         return 32; // each partition runs the 32-row kernel
-    if (T - 1 <= 128 && !fft_tail(T, D, nullptr, nullptr))
+    if (IF_FIR_FFT_SHORT_ROWS == 2 && T - 1 <= 128 && !fft_tail(T, D, nullptr, nullptr))
         return 2;
     return (T - 1 <= 256) ? 4 : (T - 1 <= 512) ? 8 : (T - 1 <= 1024) ? 16 : (T - 1 <= 2048) ? 32 : 48;
 }
@@ -1753,8 +1923,10 @@ hipError_t launch_fft(const LaunchArgs &a)
         return launch_fft_two_partitions(a);
     // (the filter bank's decimations are even: never 2 rows)
     int rows = fft_overlap_rows(a.T, a.D);
-    if (rows == 2 && (a.diag & 1024)) // development (A/B runs): the 4-row kernel for short filters as before round 4
-        rows = 4;
+    // development (A/B runs), diag 1024: filters of at most 129 taps on the full-rate pipeline take the other of the two block
+    // lengths (2 <-> 4 overlap rows)
+    if ((a.diag & 1024) && a.T - 1 <= 128 && !fft_tail(a.T, a.D, nullptr, nullptr) && !a.chan)
+        rows = rows == 2 ? 4 : 2;
     switch (rows)
     {
     case 2: return launch_fft_rows<2>(a);
@@ -1763,6 +1935,38 @@ hipError_t launch_fft(const LaunchArgs &a)
     case 16: return launch_fft_rows<16>(a);
     case 32: return launch_fft_rows<32>(a);
     default: return launch_fft_rows<48>(a);
+    }
+}
+
+// (cos, tan) form of the twiddle exp(j th): (c, t) with c = cos th rounded to float32 and t = sin th / c; an exact zero of the
+// cosine is stored as +-2^-30 (its own contribution is below rounding, the tangent stays finite).  c_ref != 0: the first
+// component is c / c_ref instead (third input of a radix-4 butterfly, see bfly4_tw).
+static double tan_cos(double th)
+{
+    double c = cos(th);
+    if (fabs(c) < 9.3e-10)
+        c = (c < 0.0 ? -1.0 : 1.0) * 9.313225746154785e-10;
+    return (double)(float)c;
+}
+static void tan_entry(double th, double c_ref, float *e)
+{
+    const double c = tan_cos(th);
+    e[1] = (float)(sin(th) / c);
+    e[0] = (float)(c_ref != 0.0 ? c / c_ref : c);
+}
+// the 15 table entries of fft16_tw for the base twiddle exp(j th): entry k at out[2 * k * stride]
+static void tan_fft16_entries(double th, float *out, int stride)
+{
+    const double w16 = -6.283185307179586476925286766559 / 16.0;
+    tan_entry(4.0 * th, 0.0, out);
+    tan_entry(8.0 * th, 0.0, out + 2 * stride);
+    tan_entry(12.0 * th, tan_cos(4.0 * th), out + 4 * stride);
+    for (int q = 0; q < 4; q++)
+    {
+        const double b = th + w16 * q;
+        tan_entry(b, 0.0, out + 2 * (3 + 3 * q) * stride);
+        tan_entry(2.0 * b, 0.0, out + 2 * (4 + 3 * q) * stride);
+        tan_entry(3.0 * b, tan_cos(b), out + 2 * (5 + 3 * q) * stride);
     }
 }
 
@@ -1922,9 +2126,47 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                         re += h[0] * ct[e] - h[1] * st[e];
                         im += h[0] * st[e] + h[1] * ct[e];
                     }
+#if IF_FIR_FFT_TAN
+                    {
+                        // G' = b^m0 G, b = W4096^(k0 + 16 k1): the factor the first stage of pass 3 still owes (see the kernel)
+                        const int eb = (m0 * ((4 * (lane / 16) + i) + 16 * (lane % 16))) & 4095;
+                        const double gr = re * ct[eb] - im * st[eb], gi = re * st[eb] + im * ct[eb];
+                        re = gr;
+                        im = gi;
+                    }
+#endif
                     hp[2 * ((i * 16 + 4 * m0 + q) * 64 + lane) + 0] = (float)re;
                     hp[2 * ((i * 16 + 4 * m0 + q) * 64 + lane) + 1] = (float)im;
                 }
+#if IF_FIR_FFT_TAN
+    // the decimate-by-4 kernels' twiddles in (cos, tan) form, in the slots of the tables they replace (LDS map at the top)
+    for (int e = 0; e < 2 * 4096; e++)
+        tw1[e] = 0.0f;
+    for (int e = 0; e < 2 * 256; e++)
+        tw2[e] = 0.0f;
+    for (int e = 0; e < 2 * 1024; e++)
+        twd[e] = twe[e] = 0.0f;
+    for (int i = 0; i < 4; i++)
+    {
+        for (int lane = 0; lane < 64; lane++)
+        {
+            // pass 3, first stage: b = W4096^(k0 + 16 k1); only entries 0..2 (b^4, b^8, b^12) are used
+            float all[30];
+            tan_fft16_entries(-PI2 * (double)((4 * (lane / 16) + i) + 16 * (lane % 16)) / 4096.0, all, 1);
+            for (int e = 0; e < 3; e++)
+            {
+                tw1[2 * ((i * 3 + e) * 64 + lane) + 0] = all[2 * e];
+                tw1[2 * ((i * 3 + e) * 64 + lane) + 1] = all[2 * e + 1];
+            }
+        }
+        for (int g = 0; g < 4; g++) // pass 2: b = W256^k0, k0 = 4 g + i
+            tan_fft16_entries(-PI2 * (double)(4 * g + i) / 256.0, tw2 + 2 * (i * 60 + g), 4);
+    }
+    for (int lane = 0; lane < 64; lane++) // inverse, last pass: b = W1024^lane
+        tan_fft16_entries(-PI2 * (double)lane / 1024.0, twd + 2 * lane, 64);
+    for (int mu2 = 0; mu2 < 4; mu2++) // inverse, middle pass: b = W64^mu2
+        tan_fft16_entries(-PI2 * (double)mu2 / 64.0, twe + 2 * mu2, 4);
+#endif
 }
 
 #endif // host side

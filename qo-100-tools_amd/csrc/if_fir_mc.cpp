@@ -459,7 +459,7 @@ IF_FIR_API uint8_t if_fir_mc_set_input_format(if_fir_mc_ctx_t *pCtx, uint32_t ul
 // the next chunk is queued ahead of the gather of this one, so the links stay busy while the owners filter.  Inside a
 // group the operations between a pair of ranks are posted in channel order on both sides (RCCL matches them in order).
 // STATUS: every rank that owns a channel sends one 4-byte word (0 = its filters succeeded) to the root.
-// A chunk is a multiple of the block advance of THIS filter's overlap-save kernel (3968, 3840, 3584, 3072, 2048 or 1024 samples,
+// A chunk is a multiple of the block advance of THIS filter's overlap-save kernel (3840, 3584, 3072, 2048 or 1024 samples,
 // if_fir::fft_block_advance) so that the blocks of a chunked call start at the same stream positions as those of an unchunked
 // one: bit-identical.  (Round 3 used one global unit, the lcm of all block advances.)
 

@@ -182,8 +182,11 @@ def bpf_design_complex(taps, centre=0.2, bandwidth=0.1, window=WINDOW_BLACKMAN):
 class IfFir:
     """One if_fir_ctx_t.  Methods mirror the C entry points."""
 
-    def __init__(self, taps, decimation=1, max_samples=1 << 20, device=0, backend=None, complex_taps=False, dev=False):
-        self._L = dev_lib() if dev else lib()
+    def __init__(self, taps, decimation=1, max_samples=1 << 20, device=0, backend=None, complex_taps=False, dev=False,
+                 lib_path=None):
+        # lib_path (development tools only, tools/ab_inproc.py): another build of the development library, loaded beside the
+        # default one so that two builds can be timed alternately in one process
+        self._L = _load(os.path.abspath(lib_path), True) if lib_path else dev_lib() if dev else lib()
         taps = np.asarray(taps)
         if np.iscomplexobj(taps):
             taps = np.ascontiguousarray(taps.astype(np.complex64)).view(np.float32)

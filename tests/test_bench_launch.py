@@ -62,3 +62,38 @@ def test_scatter_legs_are_rehearsed_over_gloo():
         sg, mc = line["extra"]["scatter_gather"], line["extra"]["scatter_gather_mc"]
         assert sg["ok"] is True and sg["channels"] == int(gpus)
         assert mc["ok"] is True and mc["chunks"] == 3 and mc["channels"] == int(gpus) + 1 and mc["groups"] == 7
+        # the record the first multi-GPU box must produce in one go -- per-rank times, bytes through
+        # ncclSend / ncclRecv, bit-identity per channel -- has a fixed schema, filled here from the gloo rehearsal; the bytes
+        # its formula states per rank are the bytes of that rank's transfer plan
+        chk = mc["multi_gpu_check"]
+        assert tuple(chk) == bench_keys() and chk["world"] == int(gpus) and chk["channels"] == int(gpus) + 1
+        assert len(chk["per_rank_ms"]) == chk["calls"] == 1 and len(chk["per_rank_ms"][0]) == int(gpus)
+        assert len(chk["bytes_sent_per_rank"]) == len(chk["bytes_received_per_rank"]) == int(gpus)
+        assert sum(chk["bytes_sent_per_rank"]) == sum(chk["bytes_received_per_rank"]) == chk["bytes_through_send_recv"] > 0
+        assert chk["channels_identical"] == [True] * (int(gpus) + 1) and chk["ok"] is True
+        assert mc["plan_bytes_agree_with_record"] is True
+
+
+def bench_keys():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_keys", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.MULTI_GPU_CHECK_KEYS
+
+
+def test_multi_gpu_check_record_schema_and_bytes():
+    """The record's byte accounting for BASELINE configs[3] (8 channels x 2^28 samples, decimation 4, 8 ranks): seven channels
+    travel, 2 GiB each way in and 512 MiB back, plus seven 4-byte status words."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_rec", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 1 << 28
+    rec = bench.multi_gpu_check_record(8, 8, n, 255, 4, "rccl", [[10.0] * 8, [9.0, 9.5] + [9.1] * 6], [True] * 8)
+    assert tuple(rec) == bench.MULTI_GPU_CHECK_KEYS and rec["ok"] is True and rec["end_to_end_ms"] == 9.5
+    assert rec["bytes_sent_per_rank"][0] == 7 * n * 8 and rec["bytes_received_per_rank"][0] == 7 * (n // 4) * 8 + 7 * 4
+    assert rec["bytes_sent_per_rank"][3] == (n // 4) * 8 + 4 and rec["bytes_received_per_rank"][3] == n * 8
+    assert rec["bytes_through_send_recv"] == 7 * n * 8 + 7 * (n // 4) * 8 + 28
+    rec = bench.multi_gpu_check_record(2, 3, 1000, 255, 4, "x", [[1.0, 2.0]], [True, False, True])
+    assert rec["ok"] is False

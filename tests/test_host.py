@@ -140,11 +140,43 @@ def test_overlap_save_tables_against_numpy(fir, t, d, ctaps):
     lane = np.arange(64)
     W = lambda n, e: np.exp(-2j * np.pi * (np.asarray(e) % n) / n)   # noqa: E731
     # twiddles
-    for rho in range(4):
-        for k0 in range(16):
-            assert np.allclose(tab["tw1"][(rho * 16 + k0) * 64:(rho * 16 + k0) * 64 + 64], W(4096, (lane + 64 * rho) * k0), atol=1e-7)
-    for k1 in range(16):
-        assert np.allclose(tab["tw2"][k1 * 16:k1 * 16 + 16], W(256, np.arange(16) * k1), atol=1e-7)
+    if d != 4:
+        for rho in range(4):
+            for k0 in range(16):
+                assert np.allclose(tab["tw1"][(rho * 16 + k0) * 64:(rho * 16 + k0) * 64 + 64], W(4096, (lane + 64 * rho) * k0), atol=1e-7)
+        for k1 in range(16):
+            assert np.allclose(tab["tw2"][k1 * 16:k1 * 16 + 16], W(256, np.arange(16) * k1), atol=1e-7)
+    else:
+        # round 4: the decimate-by-4 kernels take their twiddles in (cos, tan) form, w = c (1 + j t) stored as (c, t), on the
+        # INPUTS of the 16-point transforms: 15 entries per base twiddle b -- b^4, b^8, b^12 (the third as (c3 / c1, t3)), then for
+        # q = 0..3 the three twiddles (b W16^q)^1..3 (fft16_tw in csrc/if_fir_fft.hip)
+        def triple(e1, e2, e3):
+            c1, t1 = e1.real.astype(np.float64), e1.imag.astype(np.float64)
+            c2, t2 = e2.real.astype(np.float64), e2.imag.astype(np.float64)
+            r3, t3 = e3.real.astype(np.float64), e3.imag.astype(np.float64)
+            return c1 * (1 + 1j * t1), c2 * (1 + 1j * t2), r3 * c1 * (1 + 1j * t3)
+
+        def check_entries(entries, base):           # entries: (15, n) complex64 = (c, t) pairs; base: (n,) complex
+            w = triple(entries[0], entries[1], entries[2])
+            for k, got in zip((4, 8, 12), w):
+                assert np.allclose(got, base ** k, atol=3e-7), k
+            for q in range(4):
+                b = base * W(16, q)
+                w = triple(entries[3 + 3 * q], entries[4 + 3 * q], entries[5 + 3 * q])
+                for k, got in zip((1, 2, 3), w):
+                    assert np.allclose(got, b ** k, atol=3e-7), (q, k)
+            assert np.all(np.isfinite(entries.view(np.float32)))
+
+        g, m = lane // 16, lane % 16
+        for i in range(4):
+            base3 = W(4096, (4 * g + i) + 16 * m)       # pass 3: only the first-stage entries are kept
+            e = tab["tw1"][i * 3 * 64:(i * 3 + 3) * 64].reshape(3, 64)
+            w = triple(e[0], e[1], e[2])
+            for k, got in zip((4, 8, 12), w):
+                assert np.allclose(got, base3 ** k, atol=3e-7), (i, k)
+            check_entries(tab["tw2"][i * 60:(i + 1) * 60].reshape(15, 4), W(256, 4 * np.arange(4) + i))     # pass 2: b = W256^k0
+        check_entries(tab["twd"][:15 * 64].reshape(15, 64), W(1024, lane))                                  # inverse, last pass
+        check_entries(tab["twe"][:15 * 4].reshape(15, 4), W(64, np.arange(4)))                              # inverse, middle pass
     r = np.arange(64, dtype=np.uint64)
     ph = ((r * np.uint64(64) * np.uint64(nco_delta)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 2.0 ** 32
     assert np.allclose(tab["ncob"], np.exp(2j * np.pi * ph), atol=1e-7)
@@ -163,15 +195,18 @@ def test_overlap_save_tables_against_numpy(fir, t, d, ctaps):
         return
     # merged table: for random pass-2 outputs t[m] (m = time digit of the last 16-point transform),
     #   sum_p H(q + 4p) * FFT16(t)[q + 4p]  ==  sum_m0 y[q][m0] * G[m0][q],   y[q][m0] = sum_m1 t[m0 + 4 m1] W4^(m1 q)
+    # (round 4: the inputs of that transform still carry b^n2, b = W4096^(k0 + 16 k1) -- the twiddles of passes 1 and 2, moved to
+    # its inputs; the first stage applies b^(4 m1) inside its butterflies and the table holds G' = b^m0 G)
     G = hp                                                    # entry (i, 4*m0 + q, lane)
     tt = rng.standard_normal((4, 16, 64)) + 1j * rng.standard_normal((4, 16, 64))
     for i in range(4):
-        Y = np.fft.fft(tt[i], axis=0)                         # over the time digit
+        b3 = W(4096, (4 * (lane // 16) + i) + 16 * (lane % 16))
+        Y = np.fft.fft(tt[i] * b3[None, :] ** np.arange(16)[:, None], axis=0)      # over the time digit
         want = np.stack([sum(Hp[i, q + 4 * p] * Y[q + 4 * p] for p in range(4)) for q in range(4)])
         y = np.zeros((4, 4, 64), dtype=np.complex128)          # y[q][m0]
         for q in range(4):
             for m0 in range(4):
-                y[q, m0] = sum(tt[i, m0 + 4 * m1] * W(4, m1 * q) for m1 in range(4))
+                y[q, m0] = sum(tt[i, m0 + 4 * m1] * b3 ** (4 * m1) * W(4, m1 * q) for m1 in range(4))
         got = np.stack([sum(y[q, m0] * G[i, 4 * m0 + q] for m0 in range(4)) for q in range(4)])
         assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want)), (i, np.max(np.abs(got - want)))
     # filter-bank identity: a channel at slot s uses G_s[m0][q] = W16^(m0 s) G[m0][(q - s) mod 4],
@@ -181,7 +216,8 @@ def test_overlap_save_tables_against_numpy(fir, t, d, ctaps):
         for i in range(4):
             for m0 in range(4):
                 for q in range(4):
-                    direct = W(16, m0 * q) * sum(Hs[_bin_of(i, q + 4 * p, lane)] * W(4, m0 * p) for p in range(4))
+                    b3 = W(4096, (4 * (lane // 16) + i) + 16 * (lane % 16))
+                    direct = b3 ** m0 * W(16, m0 * q) * sum(Hs[_bin_of(i, q + 4 * p, lane)] * W(4, m0 * p) for p in range(4))
                     via = W(16, m0 * s) * G[i, 4 * m0 + ((q - s) % 4)]
                     assert np.max(np.abs(direct - via)) <= 3e-7 * scale, (s, i, m0, q)
 

@@ -137,8 +137,6 @@ def block_advance(taps, decim):
     """if_fir::fft_block_advance: new input samples per block of the overlap-save kernel for this filter"""
     if taps > 3073:
         return 2048                                   # two partitions, each on the 32-row kernel
-    if taps - 1 <= 128 and decim % 2 == 1:
-        return 4096 - 128                             # round 4: 2 overlap rows on the full-rate pipeline
     rows = 4 if taps - 1 <= 256 else 8 if taps - 1 <= 512 else 16 if taps - 1 <= 1024 else 32 if taps - 1 <= 2048 else 48
     return 4096 - 64 * rows
 

@@ -7,6 +7,12 @@ launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-a
 Rank 0 synthesises every channel on its GPU, all ranks call if_fir_mc_process_device() twice (streaming state per
 channel), rank 0 compares every channel with a single-channel context run locally on the same input and prints the
 scatter+filter+gather time.  The RCCL bootstrap id travels through torch.distributed (any other transport would do).
+
+Runs unattended and ends with ONE JSON line on stdout (rank 0; everything else goes to stderr):
+  {"mc_selfcheck": <bench.multi_gpu_check_record: per-rank ms of both calls, bytes through ncclSend/ncclRecv per rank,
+                    bit-identity per channel, ok>}
+exit code 0 iff every channel was bit-identical on both calls.  On the first 8-GPU node:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29544 tools/mc_selfcheck.py 8 28
 """
 import os
 import sys
@@ -19,6 +25,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import __graft_entry__ as g  # noqa: E402
+import bench  # noqa: E402
+import json  # noqa: E402
 
 
 def main():
@@ -57,7 +65,7 @@ def main():
     try:
         mc_ctx = fir.IfFirMc(taps, d, n, device=local, rank=rank, world=world, unique_id=uid, dev=loopback)
     except fir.IfFirError as e:
-        print("rank %d: if_fir_mc_init failed: %s" % (rank, e), flush=True)
+        print("rank %d: if_fir_mc_init failed: %s" % (rank, e), file=sys.stderr, flush=True)
         sys.exit(2)
     with mc_ctx as mc:
         ins = outs = None
@@ -71,6 +79,7 @@ def main():
             outs = [torch.zeros(2 * m, dtype=torch.float32, device="cuda") for _ in range(channels)]
             torch.cuda.synchronize()
         ok = True
+        per_rank, identical_all = [], None
         for call in range(2):
             if world > 1:
                 dist.barrier()
@@ -78,8 +87,15 @@ def main():
             got = mc.process_device([x.data_ptr() for x in ins] if rank == 0 else None,
                                     [y.data_ptr() for y in outs] if rank == 0 else None, n)
             dt = time.perf_counter() - t0
+            if world > 1:
+                t_all = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+                dist.all_gather(t_all, torch.tensor([dt * 1e3], dtype=torch.float64, device="cuda"))
+                per_rank.append([float(v[0]) for v in t_all])
+            else:
+                per_rank.append([dt * 1e3])
             if rank == 0:
                 assert got == m
+                identical = []
                 for c in range(channels):
                     with fir.IfFir(taps[c], d, 0, device=local) as f:
                         ref = torch.empty_like(outs[c])
@@ -87,13 +103,23 @@ def main():
                             f.process_device(ins[c].data_ptr(), ref.data_ptr(), n)
                         f.synchronize()
                     same = bool(torch.equal(ref, outs[c]))
+                    identical.append(same)
                     ok = ok and same
                     if not same:
                         print("call %d channel %d (rank %d): MISMATCH max |diff| %g" %
-                              (call, c, fir.mc_owner(c, world), (ref - outs[c]).abs().max().item()))
+                              (call, c, fir.mc_owner(c, world), (ref - outs[c]).abs().max().item()), file=sys.stderr)
+                identical_all = identical if identical_all is None else [a and b for a, b in zip(identical_all, identical)]
                 print("call %d: %d channels x 2^%d samples over %d ranks%s: %.2f ms (%.1f GS/s end to end) %s" %
                       (call, channels, int(np.log2(n)), world, " (LOOPBACK: %s virtual ranks, real librccl)" % os.environ["IF_FIR_MC_LOOPBACK"] if loopback else "",
-                       dt * 1e3, channels * n / dt / 1e9, "OK" if ok else "FAIL"))
+                       dt * 1e3, channels * n / dt / 1e9, "OK" if ok else "FAIL"), file=sys.stderr)
+        if rank == 0:
+            vworld = int(os.environ["IF_FIR_MC_LOOPBACK"]) if loopback else world
+            vworld = 2 if loopback and vworld == 1 else vworld
+            rec = bench.multi_gpu_check_record(vworld, channels, n, t, d,
+                                               "rccl loopback: one process plays all %d ranks over a one-rank communicator" % vworld
+                                               if loopback else "rccl (ncclSend/ncclRecv inside libif_fir.so)", per_rank, identical_all)
+            sys.stdout.write(json.dumps({"mc_selfcheck": rec}) + "\n")
+            sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
