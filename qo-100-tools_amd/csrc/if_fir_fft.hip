@@ -253,8 +253,15 @@ static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 #ifndef IF_FIR_FFT_SHORT_ROWS
 #define IF_FIR_FFT_SHORT_ROWS 4
 #endif
-#ifndef IF_FIR_FFT_EDGE_MIN
-#define IF_FIR_FFT_EDGE_MIN 0 // (A/B builds: at least this many first / last rows of a block keep the default cache policy)
+// Row loads: the first and last EDGE rows of a block keep the default cache policy, the rows in between are `nt`.  EDGE is at
+// least the block overlap (the neighbouring block finds the shared rows in L2, round 2) and, on the full-rate pipeline, at least
+// IF_FIR_FFT_EDGE_MIN_FULL rows (round 4, profiles/r04_edge_rows.txt: configs[1] 0.2093 -> 0.1999 ms with 16 rows each side
+// cached, 0.2151 with all rows cached; the decimating tails are fastest with the overlap rows alone: 255 taps / 4 +2 % at 8).
+#ifndef IF_FIR_FFT_EDGE_MIN_FULL
+#define IF_FIR_FFT_EDGE_MIN_FULL 16
+#endif
+#ifndef IF_FIR_FFT_EDGE_MIN_DEC
+#define IF_FIR_FFT_EDGE_MIN_DEC 0
 #endif
 #ifndef IF_FIR_FFT_TAN
 #define IF_FIR_FFT_TAN 1 // 0: the decimate-by-4 kernels in round 3's form (A/B builds)
@@ -264,7 +271,10 @@ constexpr int LDS_QPTR = LDS_Q + 16 + Q_RING * 8; // 16-slot bank: the 16 output
 constexpr int LDS_QNCO = LDS_QPTR + 16 * 8; // bank tails with an NCO: the block's rotation phasor, one 8-byte word per wave
 // tail phase of the queue (short launches): tail word (8 B) and the four SIMDs' claim counters (4 x 4 B)
 constexpr int LDS_QTAIL = LDS_QNCO + FFT_WAVES * 8, LDS_QCLAIM = LDS_QTAIL + 16;
-constexpr int FFT_LDS_BYTES = LDS_QCLAIM + 16;
+// filter bank at decimation 8 (round 4): W16^(a s), s = 0..15, a = 0..7 (1 KB) and per channel the 16 row phasors of its mix-down
+// (CHAN_MAX x 16 entries), both computed by the workgroup at the start of the launch
+constexpr int LDS_W16T = LDS_QCLAIM + 16, LDS_ROWT = LDS_W16T + 128 * 8;
+constexpr int FFT_LDS_BYTES = LDS_ROWT + CHAN_MAX * 16 * 8;
 static_assert(FFT_LDS_BYTES <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 
 __device__ __forceinline__ void exchange1_fwd(cf (&r)[64])
@@ -669,6 +679,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L; // outputs per block (per channel)
     constexpr int EARLY_GROUPS = IF_FIR_FFT_EARLY_GROUPS; // dec4: batches of next-block loads issued during pass 3
     constexpr int LAUX = IF_FIR_FFT_LOAD_AUX(OVL_ROWS); // cache policy of the row loads
+    constexpr int EDGE_MIN = DEC4 ? IF_FIR_FFT_EDGE_MIN_DEC : IF_FIR_FFT_EDGE_MIN_FULL;
+    constexpr int EDGE = OVL_ROWS < EDGE_MIN ? EDGE_MIN : OVL_ROWS; // first / last rows of a block loaded with the default policy
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -698,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             for (int rho = 0; rho < 4; rho++)
 #pragma unroll
                 for (int j = 0; j < 16; j++)
-                    load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, srd, lane, 4 * j + rho);
+                    load_row<I16, LAUX, EDGE>(r, srd, lane, 4 * j + rho);
             loaded = true;
         }
     }
@@ -727,6 +739,21 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         {
             if (threadIdx.x < 16)
                 reinterpret_cast<float2 **>(smem + LDS_QPTR)[threadIdx.x] = chan.out[threadIdx.x];
+        }
+        if constexpr (CHAN == 8)
+        {
+            // slot twiddles W16^(a s) = exp(-j 2 pi a s / 16) and, per channel, the phasors of output rows 0..15 of a block:
+            // row k is 32 outputs = 256 input samples behind row 0
+            if (threadIdx.x < 128)
+            {
+                const float2 w = nco_phasor(0u - ((((threadIdx.x >> 3) * (threadIdx.x & 7)) & 15u) << 28));
+                reinterpret_cast<cf *>(smem + LDS_W16T)[threadIdx.x] = (cf){w.x, w.y};
+            }
+            if (threadIdx.x < 16u * chan.count)
+            {
+                const float2 w = nco_phasor(0u - chan.pword[threadIdx.x >> 4] * 256u * (threadIdx.x & 15u));
+                reinterpret_cast<cf *>(smem + LDS_ROWT)[threadIdx.x] = (cf){w.x, w.y};
+            }
         }
         // block queue (if_fir_fft_queue.h): the current-group word and the look-ahead ring
         if (threadIdx.x < Q_RING)
@@ -835,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int rho = 0; rho < 4; rho++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, srd, lane, 4 * j + rho);
+                        load_row<I16, LAUX, EDGE>(r, srd, lane, 4 * j + rho);
             }
             else
             {
@@ -950,7 +977,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
         // filter-bank tails with an NCO: the block's share of the output rotation, phasor(phi0 + delta obase), wave-uniform;
         // parked in a per-wave LDS word until the tails need it (the 16-slot tail has neither SGPRs nor VGPRs to spare)
-        if constexpr (NCO && (CHAN == 8 || CHAN == 16))
+        if constexpr (NCO && CHAN == 16)
         {
             const float2 pb = nco_phasor(nco_phi0 + nco_delta * (uint32_t)obase);
             if (lane == 0)
@@ -1003,7 +1030,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int q = 0; q < 4; q++)
-                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, 4 * b + q));
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, 4 * b + q));
                 }
                 if (wanted)
                 {
@@ -1040,7 +1067,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int q = 0; q < 4; q++)
-                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, 4 * b + q));
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, 4 * b + q));
                 }
             }
         }
@@ -1067,7 +1094,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 8; j < 16; j++)
-                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
                 }
             }
             // 2048-point inverse as TWO 1024-point inverses (even and odd outputs), so that every lane ends up with two
@@ -1172,7 +1199,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 8; j++)
-                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
             }
             unsigned vo128 = (unsigned)lane * 16u;
             if constexpr (CHAN == 2)
@@ -1224,6 +1251,16 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 }
             constexpr int MU0_FIRST = OVL_ROWS / 4;
             const int nch = (int)chan.count;
+            static_assert(!NCO, "decimation 8: one instantiation; the context's NCO is part of the channels' mix-down words");
+            // Round 4: every channel has its own centre bin B = 256 s + b (the prototype moved up by B / 4096 cycles/sample: b = 0
+            // is round 3's slot grid).  H_c(k) = H(k - B): with k = k_low + 256 k2 (k_low = k0 + 16 k1 < 256 held by this lane and
+            // group) k_low - b = kappa - 256 cy, so the lane needs the table entries of low index kappa -- group (i - b) mod 4, the
+            // lanes rotated: a permutation, conflict-free -- for the slot s' = s + cy (tools/fft_model.py bank8_bins):
+            //   Z_c(k2') = sum_a w_{k2'}[a] W16^(a s') G_q^kappa[a],  q = (k2' - s') mod 2
+            // k_low >> 2 = lane / 16 + 4 (lane % 16) in every group
+            const int lq = (lane >> 4) + 4 * (lane & 15);
+            const f2v *w16t = reinterpret_cast<const f2v *>(smem + LDS_W16T);
+            const f2v *rowt = reinterpret_cast<const f2v *>(smem + LDS_ROWT);
             for (int cp = 0; cp < nch; cp += 2)
             {
                 const bool last = cp + 2 >= nch; // the w values die with the last pair: refill with the next block
@@ -1241,17 +1278,24 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                             continue;
                         }
                         const int c = cp + ch;
-                        const int par = (int)chan.slot[c] & 1;
-                        const f2v *g0 = hp + (i * 16 + 8 * par) * 64 + lane;       // k2' = 0: q = s & 1       (+ a * 64 entries)
-                        const f2v *g1 = hp + (i * 16 + 8 * (1 - par)) * 64 + lane; // k2' = 1: q = (1 - s) & 1
+                        const int cb = (int)chan.bin[c], b = cb & 255, s = cb >> 8; // wave-uniform
+                        const int ik = (i - b) & 3;                                 // table group of kappa (kappa % 4)
+                        const int d = lq - (b >> 2) - ((i < (b & 3)) ? 1 : 0);      // (k_low - b) >> 2, negative: a borrow from k2
+                        const int lk = d & 63;
+                        const int lane_k = ((lk & 3) << 4) | (lk >> 2);             // the lane that holds kappa in group ik
+                        const int sp = (s + (d < 0 ? 1 : 0)) & 15;
+                        const int par = sp & 1;
+                        const f2v *g0 = hp + (ik * 16 + 8 * par) * 64 + lane_k;       // k2' = 0: q = s' & 1       (+ a * 64 entries)
+                        const f2v *g1 = hp + (ik * 16 + 8 * (1 - par)) * 64 + lane_k; // k2' = 1: q = (1 - s') & 1
+                        const f2v *twp = w16t + sp * 8;
                         cf z0 = cmul_v<false>(r[phys(i, 0)], g0[0]);
                         cf z1 = cmul_v<false>(r[phys(i, 8)], g1[0]);
 #pragma unroll
                         for (int a8 = 1; a8 < 8; a8++)
                         {
-                            const cf tw = {chan.tw[c][2 * (a8 - 1)], chan.tw[c][2 * (a8 - 1) + 1]};
-                            z0 = cmac_v(z0, cmul_s<false>(r[phys(i, a8)], tw), g0[a8 * 64]);
-                            z1 = cmac_v(z1, cmul_s<false>(r[phys(i, a8 + 8)], tw), g1[a8 * 64]);
+                            const cf tw = twp[a8];
+                            z0 = cmac_v(z0, cmul_v<false>(r[phys(i, a8)], tw), g0[a8 * 64]);
+                            z1 = cmac_v(z1, cmul_v<false>(r[phys(i, a8 + 8)], tw), g1[a8 * 64]);
                         }
                         a[4 * i + 2 * ch] = z0 + z1;
                         a[4 * i + 2 * ch + 1] = cmul_v<true>(z0 - z1, twd[(i * 4 + 2) * 64 + lane]); // conj W512^(16 k1 + k0)
@@ -1260,7 +1304,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     {
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
                     }
                 }
                 cf c[16];
@@ -1271,20 +1315,19 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
                 }
-                // mix-down: exp(-j 2 pi s a / 16), a = abs0 + n0 + 8 m: the call constant rot0 times (-1)^(s m); m = obase +
-                // 32 (mu0 - first) + 2 mu1 + mu2 with obase even, so the sign is (-1)^(s mu2)
+                // mix-down: output o = obase + 32 (mu0 - first) + 2 mu1 + mu2 of the call belongs to input sample abs0n0 + 8 o and is
+                // rotated by exp(-j 2 pi pword (abs0n0 + 8 o) / 2^32): a lane factor (exact 32-bit phase, one sincos per lane and
+                // channel pair) times the channel's row phasor (LDS table, 256 input samples per row)
                 const int chl = (lane >> 1) & 1, cl = cp + chl;
                 const int c1 = (cp + 1 < nch) ? cp + 1 : nch - 1;
                 float2 *po = chl ? chan.out[c1] : chan.out[cp];
-                const cf r0 = chl ? (cf){chan.rot0[c1][0], chan.rot0[c1][1]} : (cf){chan.rot0[cp][0], chan.rot0[cp][1]};
-                const int sl = chl ? (int)chan.slot[c1] : (int)chan.slot[cp];
-                cf wl = ((sl & lane) & 1) ? (cf){-r0.x, -r0.y} : r0;
+                const uint32_t pw = chl ? chan.pword[c1] : chan.pword[cp];
                 const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
-                if constexpr (NCO) // as in the 16-slot tail: phasor(phi0 + delta m) = [block, uniform] * [lane: entries 32..63] * B(mu0 - first)
-                    wl = cmul_v<false>(cmul_v<false>(wl, *reinterpret_cast<const cf *>(smem + LDS_QNCO + wid * 8)),
-                                       ncob[32 + 2 * (lane >> 2) + (lane & 1)]);
+                const float2 pa = nco_phasor(0u - pw * (chan.abs0n0 + 8u * (uint32_t)o0));
+                const cf wl = {pa.x, pa.y};
+                const f2v *rowp = rowt + (chl ? c1 : cp) * 16;
                 if (cl < nch && !(diag & 2))
                 {
 #pragma unroll
@@ -1293,11 +1336,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
                         if (idx < M)
                         {
-                            cf v;
-                            if constexpr (NCO)
-                                v = cmul_v<false>(c[mu0], cmul_v<false>(wl, ncob[mu0 - MU0_FIRST]));
-                            else
-                                v = cmul_v<false>(c[mu0], wl);
+                            const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
                             __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
                         }
                     }
@@ -1360,7 +1399,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     {
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
                     }
                 }
                 cf c[16];
@@ -1374,7 +1413,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
-                            load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
                 }
                 // mix-down of the decimated output: exp(-j 2 pi slot a / 16), a = abs0 + n0 + 4 m, m = obase + 64 r + lane
                 // with obase a multiple of 4: a call constant (rot0, host) times a quarter turn per lane
@@ -1435,7 +1474,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
                 }
                 }
             FFT_STAMP(5);
@@ -1451,7 +1490,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int i = EARLY_GROUPS; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, phys(i, j));
+                        load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
             }
             constexpr int MU0_FIRST = OVL_ROWS / 4; // first valid 64-output row of the decimated block
             if constexpr (NCO)
@@ -1606,7 +1645,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 {
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        load_row<I16, LAUX, (OVL_ROWS < IF_FIR_FFT_EDGE_MIN ? IF_FIR_FFT_EDGE_MIN : OVL_ROWS)>(r, nsrd, lane, 4 * j + rho);
+                        load_row<I16, LAUX, EDGE>(r, nsrd, lane, 4 * j + rho);
                 }
                 }
         }
@@ -1786,14 +1825,8 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             (a.D == 4 && (a.nco_word || a.ctaps)))
             return hipErrorInvalidConfiguration;
         const int ckey = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
-        if (a.D == 8) // per channel (pairs share a small inverse); chan->tw[] = W16^(a slot), a = 1..7
-            switch (ckey)
-            {
-            case 0: return launch_fft_t<ROWS, true, false, false, 8>(a);
-            case 1: return launch_fft_t<ROWS, true, false, true, 8>(a);
-            case 2: return launch_fft_t<ROWS, true, true, false, 8>(a);
-            default: return launch_fft_t<ROWS, true, true, true, 8>(a);
-            }
+        if (a.D == 8) // per channel (pairs share a small inverse); chan->bin[] / pword[]: centre bin and mix-down word of a channel
+            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 8>(a) : launch_fft_t<ROWS, true, false, false, 8>(a);
         if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
             switch (ckey)
             {

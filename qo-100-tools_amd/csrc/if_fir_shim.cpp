@@ -646,6 +646,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
             for (uint32_t c = 0; c < 16; c++)
                 chan->mask16 |= chan->out[c] ? (1u << c) : 0u;
         }
+        chan->abs0n0 = (uint32_t)(ctx->consumed + n0);
         a.chan = chan;
         if (ctx->D >= 8)
             a.fft_tables = ctx->d_fft_tables_bank;
@@ -689,17 +690,24 @@ IF_FIR_API uint8_t if_fir_process_device(if_fir_ctx_t *pCtx, const void *pDevIn,
 // Uniform filter bank (BUILD-DEFINED): channel c = the context's real prototype taps applied after a
 // mix-down by pulSlots[c]/16 cycles/sample, decimated by 4 -- the same result as ulChannels contexts with
 // if_fir_set_nco(slot/16), from ONE pass over the input (one forward transform per block, one small inverse per channel).
-IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots,
-                                                     const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples,
-                                                     uint64_t *pullOutSamples)
+// pdFreq != nullptr (if_fir_channelizer_process_device_freq, decimation 8): channel c is centred at pdFreq[c] cycles/sample
+// instead of on a slot
+static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots, const double *pdFreq,
+                               const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples, uint64_t *pullOutSamples)
 {
     if (!pCtx)
         return 0;
     if (pullOutSamples)
         *pullOutSamples = 0;
-    if (ulChannels < 1 || ulChannels > (uint32_t)if_fir::CHAN_MAX || !pulSlots || !ppDevOut)
+    if (ulChannels < 1 || ulChannels > (uint32_t)if_fir::CHAN_MAX || (!pulSlots && !pdFreq) || !ppDevOut)
     {
-        set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot and output arrays", if_fir::CHAN_MAX);
+        set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot (or centre) and output arrays", if_fir::CHAN_MAX);
+        return 0;
+    }
+    if (pdFreq && (pCtx->D != 8 || pCtx->nco_word))
+    {
+        set_err(pCtx, "if_fir_channelizer_process_device_freq: needs a context with decimation 8 and no NCO (every channel carries "
+                      "its own centre frequency)");
         return 0;
     }
     if ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || (pCtx->D == 4 && (pCtx->ctaps || pCtx->nco_word)) ||
@@ -718,6 +726,22 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
     chan.count = ulChannels;
     for (uint32_t c = 0; c < ulChannels; c++)
     {
+        if (pdFreq)
+        {
+            // centre of the filter: the multiple of fs/4096 nearest to the wanted frequency (the overlap-save kernel moves the
+            // prototype's response by whole bins of its 4096-point transform); mix-down: the wanted frequency itself, as a 32-bit
+            // phase word
+            if (!(pdFreq[c] >= -0.5 && pdFreq[c] <= 0.5) || (ullSamples && !ppDevOut[c]) || ((uintptr_t)ppDevOut[c] & 15))
+            {
+                set_err(pCtx, "if_fir_channelizer_process_device_freq: channel %u: centre must be within +-0.5 cycles/sample and "
+                              "the output a 16-byte aligned device pointer", c);
+                return 0;
+            }
+            chan.bin[c] = (uint32_t)(llround(pdFreq[c] * 4096.0) & 4095);
+            chan.pword[c] = (uint32_t)(int64_t)llround(pdFreq[c] * 4294967296.0);
+            chan.out[c] = (float2 *)ppDevOut[c];
+            continue;
+        }
         if (pulSlots[c] > 15 || (ullSamples && !ppDevOut[c]) || ((uintptr_t)ppDevOut[c] & 15))
         {
             set_err(pCtx, "if_fir_channelizer_process_device: channel %u: slot must be 0..15 and the output a 16-byte "
@@ -739,6 +763,10 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
         }
         chan.slot[c] = pulSlots[c];
         chan.out[c] = (float2 *)ppDevOut[c];
+        // decimation 8: a slot is the centre bin 256 slot; the context's NCO (a common fine offset: the tables are built from
+        // its effective complex taps) joins the slot's mix-down word
+        chan.bin[c] = 256u * pulSlots[c];
+        chan.pword[c] = (pulSlots[c] << 28) + pCtx->nco_word;
         for (int m0 = 1; m0 < 8; m0++) // decimation 4 uses the first three
         {
             const double a = -2.0 * M_PI * (double)((m0 * pulSlots[c]) & 15u) / 16.0; // W16^(m0 slot)
@@ -755,6 +783,28 @@ IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_
     if (!ensure_fft_tables(pCtx) || (pCtx->D != 4 && !ensure_bank_tables(pCtx)))
         return 0;
     return run_device(pCtx, pDevIn, ppDevOut[0], ullSamples, pullOutSamples, true, &chan);
+}
+
+IF_FIR_API uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots,
+                                                     const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples,
+                                                     uint64_t *pullOutSamples)
+{
+    return channelizer_run(pCtx, ulChannels, pulSlots, nullptr, pDevIn, ppDevOut, ullSamples, pullOutSamples);
+}
+
+// Channels at arbitrary centre frequencies from ONE pass over the input (round 4; decimation 8): see include/if_fir.h
+IF_FIR_API uint8_t if_fir_channelizer_process_device_freq(if_fir_ctx_t *pCtx, uint32_t ulChannels, const double *pdCentre,
+                                                          const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples,
+                                                          uint64_t *pullOutSamples)
+{
+    if (pCtx && !pdCentre)
+    {
+        set_err(pCtx, "if_fir_channelizer_process_device_freq: NULL centre array");
+        if (pullOutSamples)
+            *pullOutSamples = 0;
+        return 0;
+    }
+    return channelizer_run(pCtx, ulChannels, nullptr, pdCentre, pDevIn, ppDevOut, ullSamples, pullOutSamples);
 }
 
 IF_FIR_API uint8_t if_fir_process(if_fir_ctx_t *pCtx, const float *pfIQIn, float *pfIQOut, uint64_t ullSamples,

@@ -24,7 +24,7 @@ EXPORTS = [
     "if_fir_set_tuning", "if_fir_set_input_format", "if_fir_set_stream", "if_fir_synchronize", "if_fir_last_error", "if_fir_out_count",
     "if_fir_process", "if_fir_process_device", "if_fir_synth_device", "if_fir_dev_alloc",
     "if_fir_dev_free", "if_fir_dev_upload", "if_fir_dev_download", "if_fir_device_info",
-    "if_fir_set_nco", "if_fir_get_nco", "if_fir_channelizer_process_device", "if_fir_host_alloc", "if_fir_host_free",
+    "if_fir_set_nco", "if_fir_get_nco", "if_fir_channelizer_process_device", "if_fir_channelizer_process_device_freq", "if_fir_host_alloc", "if_fir_host_free",
     "if_fir_power_device",
     "if_fir_mc_owner", "if_fir_mc_unique_id", "if_fir_mc_init", "if_fir_mc_destroy", "if_fir_mc_reset",
     "if_fir_mc_set_input_format", "if_fir_mc_process_device", "if_fir_mc_channel_ctx", "if_fir_mc_last_error",
@@ -113,6 +113,9 @@ def _load(path, dev):
     L.if_fir_channelizer_process_device.argtypes = [vp, u32, ctypes.POINTER(u32), vp, ctypes.POINTER(vp), u64,
                                                     ctypes.POINTER(u64)]
     L.if_fir_channelizer_process_device.restype = u8
+    L.if_fir_channelizer_process_device_freq.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_double), vp, ctypes.POINTER(vp), u64,
+                                                         ctypes.POINTER(u64)]
+    L.if_fir_channelizer_process_device_freq.restype = u8
     L.if_fir_host_alloc.argtypes = [vp, ctypes.POINTER(vp), u64]
     L.if_fir_host_alloc.restype = u8
     L.if_fir_host_free.argtypes = [vp, vp]
@@ -277,6 +280,16 @@ class IfFir:
         m = ctypes.c_uint64(0)
         self._check(self._L.if_fir_process(self._ctx, ctypes.cast(iq.ctypes.data, ctypes.POINTER(ctypes.c_float)),
                                          _f32p(out), n, ctypes.byref(m)))
+        return int(m.value)
+
+    def channelizer_process_device_freq(self, centres, dev_in, dev_outs, samples):
+        """if_fir_channelizer_process_device_freq(): channel c centred at centres[c] cycles/sample (decimation 8)."""
+        k = len(centres)
+        fc = (ctypes.c_double * k)(*[float(v) for v in centres])
+        po = (ctypes.c_void_p * k)(*[ctypes.c_void_p(int(p)) for p in dev_outs])
+        m = ctypes.c_uint64(0)
+        self._check(self._L.if_fir_channelizer_process_device_freq(self._ctx, k, fc, ctypes.c_void_p(int(dev_in)), po,
+                                                                   int(samples), ctypes.byref(m)))
         return int(m.value)
 
     def channelizer_process_device(self, slots, dev_in, dev_outs, samples):

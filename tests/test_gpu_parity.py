@@ -971,6 +971,88 @@ def test_filter_bank_with_a_common_fine_offset(fir, oracle, torch_cuda, d, i16):
             f.channelizer_process_device([1], xd.data_ptr(), [xd.data_ptr()], 16)
 
 
+@pytest.mark.parametrize("t,i16", [(255, False), (1023, False), (127, True), (511, False)])
+def test_filter_bank_channels_at_arbitrary_centre_frequencies(fir, oracle, torch_cuda, t, i16):
+    """Round 4: channels at ARBITRARY centres from one pass (decimation 8): the prototype moved up by the multiple
+    of fs/4096 nearest to the wanted centre (a shift of the overlap-save transform's bins: per lane another table row, the
+    lanes rotated), mixed down by the exact centre.  Centres ON the grid: every channel against the float64 NCO oracle at that
+    frequency = what C contexts with if_fir_set_nco(f_c) compute (also checked against one such context on the GPU).  Centres
+    OFF the grid: against the by-definition float64 form  y = exp(-j 2 pi f a) (h exp(+j 2 pi g k) * x),  g = round(4096 f) / 4096.
+    Ragged pieces (history, phase and sample index carried), odd channel counts, negative centres, float32 / int16."""
+    torch = torch_cuda
+    taps = fir.bpf_design(t, 0.0, 0.02)
+    n = 120_011
+    if i16:
+        xi = np.clip(np.round(oracle.synth_iq(n, 57) * 12000.0), -32768, 32767).astype(np.int16)
+        x = xi.astype(np.float32) * np.float32(2.0 ** -15)
+        xd = torch.from_numpy(xi).cuda()
+        cuts = [0, 8, 50_008, n]
+    else:
+        x = oracle.synth_iq(n, 57)
+        xd = torch.from_numpy(x).cuda()
+        cuts = [0, 1, 40_001, 40_018, n]
+    d = 8
+    on_grid = [b / 4096.0 for b in (0, 1, 255, 256, 257, 300, 819, 2047, -2048, -1, -333, 1638, 77)]       # 13 channels
+    off_grid = [0.2, -0.123456789, 0.05 + 1.0 / 8192 - 1e-9, 0.3333333, 1e-7]
+    for centres in (on_grid, off_grid):
+        with fir.IfFir(taps, d, n) as f:
+            if i16:
+                f.set_input_format(fir.INPUT_I16)
+            parts = [[] for _ in centres]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                m_exp = oracle.out_count(a, b - a, d)
+                outs = [torch.full((2 * m_exp + 8,), 3.0, dtype=torch.float32, device="cuda") for _ in centres]
+                piece = xd[2 * a:2 * b].clone()
+                torch.cuda.synchronize()
+                assert f.channelizer_process_device_freq(centres, piece.data_ptr(), [o.data_ptr() for o in outs], b - a) == m_exp
+                f.synchronize()
+                for c in range(len(centres)):
+                    o = outs[c].cpu().numpy()
+                    assert np.all(o[2 * m_exp:] == 3.0)
+                    parts[c].append(o[:2 * m_exp])
+        xc = x[0::2].astype(np.float64) + 1j * x[1::2].astype(np.float64)
+        for c, fc in enumerate(centres):
+            got = np.concatenate(parts[c])
+            if centres is on_grid:
+                ref = oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(fc))
+            else:
+                g = np.round(fc * 4096.0) / 4096.0
+                k = np.arange(t)
+                hc = taps.astype(np.float64) * np.exp(2j * np.pi * g * k)
+                y = np.convolve(xc, hc)[:n][::d]
+                word = oracle.nco_phase_word(fc)
+                aidx = np.arange(0, n, d, dtype=np.uint64)
+                ph = ((np.uint64(word) * aidx) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 2.0 ** 32
+                y = y * np.exp(-2j * np.pi * ph)
+                ref = np.empty(2 * y.size, dtype=np.float64)
+                ref[0::2], ref[1::2] = y.real, y.imag
+            l2, mx = oracle.err_metrics(got, ref)
+            assert l2 <= TOL and mx <= TOL, (t, i16, fc, l2, mx)
+    # one on-grid channel against a single-channel context with the NCO set to that centre (the C contexts of the claim)
+    with fir.IfFir(taps, d, n) as f1:
+        if i16:
+            f1.set_input_format(fir.INPUT_I16)
+        f1.set_nco(300 / 4096.0)
+        y1 = f1.process(xi if i16 else x)
+    with fir.IfFir(taps, d, n) as f:
+        if i16:
+            f.set_input_format(fir.INPUT_I16)
+        out = torch.zeros(2 * oracle.out_count(0, n, d), dtype=torch.float32, device="cuda")
+        f.channelizer_process_device_freq([300 / 4096.0], xd.data_ptr(), [out.data_ptr()], n)
+        f.synchronize()
+        l2, mx = oracle.err_metrics(out.cpu().numpy(), y1.astype(np.float64))
+        assert l2 <= 2 * TOL and mx <= 2 * TOL, (l2, mx)
+        # refusals: an NCO on the context, another decimation, a centre outside +-0.5
+        with pytest.raises(fir.IfFirError, match="0.5"):
+            f.channelizer_process_device_freq([0.6], xd.data_ptr(), [out.data_ptr()], 16)
+        f.set_nco(0.01)
+        with pytest.raises(fir.IfFirError, match="no NCO"):
+            f.channelizer_process_device_freq([0.1], xd.data_ptr(), [out.data_ptr()], 16)
+    with fir.IfFir(taps, 16, n) as f:
+        with pytest.raises(fir.IfFirError, match="decimation 8"):
+            f.channelizer_process_device_freq([0.1], xd.data_ptr(), [xd.data_ptr()], 16)
+
+
 def test_random_configurations_against_the_oracle(fir, oracle):
     """Sweep of random (taps, decimation, length, backend, piece cuts, input format, NCO) combinations: every result
     within SPEC tolerance of the float64 oracle, the bit-exact kernels equal to their order models."""
