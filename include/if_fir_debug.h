@@ -13,8 +13,7 @@
  *                  8 / 128 cache-line touches ahead of the next block group, ...  (DESIGN.md §3.4); 256 no tail phase in
  *                  short launches; 512 the waves of workgroup 0 count a queue fault and leave as if their bounded wait had
  *                  expired: blocks stay unwritten and if_fir_synchronize must report it (the fault path's test);
- *                  1024 (round 4) filters of at most 129 taps on the full-rate pipeline with 2 overlap rows (L = 3968) instead of 4
- *                  (same results to tolerance; measured 3 % slower on BASELINE configs[1]); 2048 the queue's tail phase in launches of up to 16 two-wave rounds
+ *                  2048 (round 4) the queue's tail phase in launches of up to 16 two-wave rounds
  *   3000           decimation 2, 6, 10, ..., 62 through the full-rate kernel + selecting store instead of the decimate-by-2 tail (same results to
  *                  tolerance; A/B timing)
  *   4000           the next call fails before anything is launched (IF_FIR_DEBUG=1): lets tests reach callers' error paths
@@ -45,6 +44,10 @@ uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulW
 #define IF_FIR_DEBUG_TABLE_FLOATS 21632u
 uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
                                  uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats);
+/* host-only: the table image of the odd-decimation kernel (decimation 3, 9, 15, ...: 2 * (3 * 1024 + 2176) = 10496 floats) */
+#define IF_FIR_DEBUG_ODD_TABLE_FLOATS 10496u
+uint32_t if_fir_debug_fft_tables_odd(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
+                                     uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats);
 /* host-only: block-queue layout of an overlap-save launch: pllOut[6] = blocks per group, groups, static groups per
  * workgroup, 0, upper bound of the global ticket counter, workgroups */
 uint8_t if_fir_debug_fft_schedule(uint64_t ullBlocks, uint32_t ulWorkgroups, int64_t *pllOut);

@@ -14,9 +14,10 @@
 // waves of a 512-thread workgroup are independent; FFT blocks are handed out through an atomic queue.
 // FP32 VALU only (v_add/v_fma/v_pk_*), no MFMA.
 //
-// Build: this file is compiled six times (csrc/Makefile) -- once per overlap length with -DIF_FIR_FFT_ROWS=4|8|16|32|48 (the
+// Build: this file is compiled seven times (csrc/Makefile) -- once per overlap length with -DIF_FIR_FFT_ROWS=4|8|16|32|48 (the
 // kernel, its launcher and the explicit instantiation of launch_fft_rows<ROWS>; the 32-row unit also carries the two-partition
-// launches) and once without it (host side: tables, routing predicates, launch_fft) -- so that the 194 instantiations compile
+// launches), once with -DIF_FIR_FFT_ODD (the odd-decimation kernel) and once with neither (host side: tables, routing predicates,
+// launch_fft) -- so that the instantiations compile
 // in parallel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,6 +28,11 @@
 
 #include "if_fir_kernels.h"
 #include "if_fir_fft_queue.h"
+
+// the host side (tables, routing predicates, launch_fft) is the unit compiled without a kernel selector
+#if !defined(IF_FIR_FFT_ROWS) && !defined(IF_FIR_FFT_ODD)
+#define IF_FIR_FFT_HOST 1
+#endif
 
 namespace if_fir
 {
@@ -247,18 +253,14 @@ static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 //   LDS_TWD: inverse, last pass    [e*64 + lane]            b = W1024^lane
 //   LDS_TWE: inverse, middle pass  [e*4 + lane%4]           b = W64^(lane%4)
 //   LDS_HP : G'[m0][q] = b^m0 G[m0][q] (the factor pass 3's first stage still owes, merged into the table)
-// overlap rows of filters of at most 129 taps on the full-rate pipeline: 4 (L = 3840, as for <= 257 taps) or 2 (L = 3968).
-// Round 4 built the 2-row kernel for BASELINE configs[1] and MEASURED it 3 % slower than the 4-row one there
-// (profiles/r04_two_row_overlap.txt), so 4 stays the default; development variant 1024 runs the other one.
-#ifndef IF_FIR_FFT_SHORT_ROWS
-#define IF_FIR_FFT_SHORT_ROWS 4
-#endif
-// Row loads: the first and last EDGE rows of a block keep the default cache policy, the rows in between are `nt`.  EDGE is at
-// least the block overlap (the neighbouring block finds the shared rows in L2, round 2) and, on the full-rate pipeline, at least
-// IF_FIR_FFT_EDGE_MIN_FULL rows (round 4, profiles/r04_edge_rows.txt: configs[1] 0.2093 -> 0.1999 ms with 16 rows each side
-// cached, 0.2151 with all rows cached; the decimating tails are fastest with the overlap rows alone: 255 taps / 4 +2 % at 8).
+// Row loads: the first and last EDGE rows of a block keep the default cache policy, the rows in between are `nt`.  EDGE = the block
+// overlap (the neighbouring block finds the shared rows in L2, round 2).  Round 4 swept larger values (IF_FIR_FFT_EDGE_MIN_FULL /
+// _DEC for the full-rate pipeline / the decimating tails, profiles/r04_edge_rows.txt): 2^28-sample launches lose 2-3 % with more
+// cached rows; configs[1] (2^26 samples) GAINS 4.5 % at 16 rows each side -- half of its 512 MB input, i.e. the 256 MB
+// memory-side cache serving the same bytes again on the benchmark's next launch: an artefact of re-filtering one buffer, not a
+// property of a stream in service, so it was not adopted.
 #ifndef IF_FIR_FFT_EDGE_MIN_FULL
-#define IF_FIR_FFT_EDGE_MIN_FULL 16
+#define IF_FIR_FFT_EDGE_MIN_FULL 0
 #endif
 #ifndef IF_FIR_FFT_EDGE_MIN_DEC
 #define IF_FIR_FFT_EDGE_MIN_DEC 0
@@ -470,17 +472,19 @@ struct KeepEvery
 // other one for the launch behind it), words 2, 3 = tail ticket counters (likewise), word 4 = expired bounded waits.
 struct DevQueue
 {
-    char *smem;
+    char *qcur;   // LDS: the current-group word (8 B, 16-byte slot) followed by the look-ahead ring
+    char *qtail;  // LDS: the tail word
+    char *qclaim; // LDS: the four SIMDs' tail claim counters
     unsigned int *gqueue; // this launch's global ticket counter
     unsigned int *tqueue; // this launch's tail ticket counter
     unsigned int *faultw; // bounded waits that expired (0 in a healthy launch)
     int lane;
-    __device__ __forceinline__ unsigned long long *tailw() const { return reinterpret_cast<unsigned long long *>(smem + LDS_QTAIL); }
+    __device__ __forceinline__ unsigned long long *tailw() const { return reinterpret_cast<unsigned long long *>(qtail); }
     __device__ __forceinline__ unsigned tail_claim(unsigned simd)
     {
         unsigned c = 0;
         if (lane == 0)
-            c = __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(smem + LDS_QCLAIM) + simd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            c = __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(qclaim) + simd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return __builtin_amdgcn_readfirstlane(c);
     }
     __device__ __forceinline__ unsigned long long tail_add()
@@ -506,8 +510,8 @@ struct DevQueue
             t = atomicAdd(tqueue, 1u);
         return __builtin_amdgcn_readfirstlane(t);
     }
-    __device__ __forceinline__ unsigned long long *cur() const { return reinterpret_cast<unsigned long long *>(smem + LDS_Q); }
-    __device__ __forceinline__ unsigned long long *ring() const { return reinterpret_cast<unsigned long long *>(smem + LDS_Q + 16); }
+    __device__ __forceinline__ unsigned long long *cur() const { return reinterpret_cast<unsigned long long *>(qcur); }
+    __device__ __forceinline__ unsigned long long *ring() const { return reinterpret_cast<unsigned long long *>(qcur + 16); }
     static __device__ __forceinline__ unsigned long long uniform(unsigned long long v)
     {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -642,6 +646,348 @@ __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16],
     fft16_tw<true, 64>(c, tc + lane); // over k0 -> mu0
 }
 
+
+#ifdef IF_FIR_FFT_ODD // ================= odd decimations 3, 9, 15, ..., 63: their own compilation unit =================
+// Round 4: 4096 has no odd factor to fold by, so odd decimations ran the full-rate pipeline with a selecting store
+// (2528 packed instructions per 3840 input samples).  Here a block is F x 1024 input samples, F = 3 or 5: lane l of row r loads
+// the F consecutive samples x[s0 + F (64 r + l) + p], p = 0..F-1 -- F phase streams x_p[m] = x[s0 + F m + p] in the load layout of
+// a 1024-point transform -- and
+//     y[F m] = sum_p (g_p * x_p)[m],   g_0[k] = h[F k],  g_p[d] = h[F d - p]  (p >= 1, d >= 1: x[F m - k] = x_p[m - d] for k = F d - p)
+// is evaluated as  Z = sum_p FFT1024(x_p) G_p,  y = IFFT1024(Z):  F forward 1024-point transforms (the mirror image of the
+// decimate-by-4 kernel's small inverse, twiddles in (cos, tan) form on the inputs), F x 16 complex MACs per lane and ONE
+// inverse -- 3 x 212 + 96 + 208 = 940 packed instructions per 2688 input samples at F = 3 (tools/fft_model.py odd_block).
+// The first 64 OVLR outputs of a block are dropped (OVLR = 2, 4 or 8 rows: (T - 1 + F - 1) / F <= 64 OVLR).  Decimations F x sub
+// (9, 15, 21, ...; 25, 35, 55) keep every sub-th output of this tail (KeepEvery, as behind the even tails).
+// LDS image (fft_build_tables_odd): G_p [(p*16 + slot)*64 + lane] | TB [e*16 + k0] (forward middle pass, b = W256^k0) |
+// TC [(i*3 + e)*64 + lane] (forward last pass, b = W1024^(k0 + 16 k1)) | TWD, TWE (the inverse's tables, as in the decimate-by-4
+// image) | NCO row phasors
+constexpr int ODD_LDS_G = 0;
+template <int F> struct OddLds
+{
+    static constexpr int TB = F * 16 * 64 * 8, TC = TB + 2048, TWD = TC + 4 * 3 * 64 * 8, TWE = TWD + 8192, NCO = TWE + 512,
+                         XB = NCO + 512, Q = XB + FFT_WAVES * XBUF, QTAIL = Q + 16 + Q_RING * 8, QCLAIM = QTAIL + 16, BYTES = QCLAIM + 16;
+    static_assert(XB == fft_odd_table_floats(F) * 4, "odd table image size");
+    static_assert(BYTES <= 160 * 1024, "LDS");
+};
+
+// forward 1024-point transform of v (reg[row] = x[64 row + lane]) into z (slot 4 i + k2', lane (g, k1): X[k0 + 16 k1 + 256 k2'],
+// k0 = 4 g + i): FFT16 over the rows (plain) -> Y^-1 -> FFT16 over mu1, inputs carry (W256^k0)^mu1 -> X^-1 -> 4-point DFT over
+// mu2, inputs carry (W1024^(k0 + 16 k1))^mu2
+__device__ __forceinline__ void forward_1024_tan(cf (&v)[16], cf (&z)[16], const f2v *tb, const f2v *tc, char *xb, int lane)
+{
+    const int g = lane >> 4, m = lane & 15;
+    fft16<false>(v); // over mu0 -> k0; lane = 4 mu1 + mu2
+    cf y[16];
+    {
+        // Y^-1: element k0 of lane 4 mu1 + mu2 -> lane (k0, mu2), slot mu1 (the addresses of inverse_tail256's Y, roles swapped)
+        char *wr = xb + (lane & 3) * XREG + (lane >> 2) * XROW;      // + k0*8
+        const int k0 = 4 * g + (m >> 2), low = m & 3;
+        const char *rd = xb + low * XREG + k0 * 8;                   // + mu1*XROW
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            *reinterpret_cast<f2v *>(wr + j * 8) = v[j];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            y[j] = *reinterpret_cast<const f2v *>(rd + j * XROW);
+        fft16_tw<false, 16>(y, tb + k0); // over mu1 -> k1
+    }
+    {
+        // X^-1 (the row transposition is its own inverse): element k1 of lane (g, j) -> lane (g, k1), slot j = 4 i + mu2
+        char *wr = xb + g * XREG + m * 8;
+        const char *rd = xb + g * XREG + m * XROW;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            *reinterpret_cast<f2v *>(wr + j * XROW) = y[j];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            y[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const cf e1 = tc[(i * 3 + 0) * 64 + lane], e2 = tc[(i * 3 + 1) * 64 + lane], e3 = tc[(i * 3 + 2) * 64 + lane];
+        bfly4_tw<false>(y[4 * i], y[4 * i + 1], y[4 * i + 2], y[4 * i + 3], e1, e2, e3, z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]);
+    }
+}
+
+template <int F, int OVLR, bool I16, bool NCO, bool SUB>
+__global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
+                                                        const f2v *__restrict__ tables, const f2v *__restrict__ hist, int HL, int64_t N,
+                                                        int32_t n0, int64_t M, int64_t nblocks, unsigned int *queue, int32_t diag,
+                                                        uint32_t nco_phi0, uint32_t nco_delta, uint32_t qsel, void *__restrict__ hist_out,
+                                                        uint32_t sub, int64_t decn_m)
+{
+    using L = OddLds<F>;
+    constexpr int ISZ = I16 ? 4 : 8;
+    constexpr int LOUT = 1024 - 64 * OVLR, LIN = F * LOUT, OVL = F * 64 * OVLR;
+    constexpr bool LATE_LAST = NCO && SUB && !I16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const char *in = reinterpret_cast<const char *>(in_);
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {
+        const f4v_t *src = reinterpret_cast<const f4v_t *>(tables);
+        f4v_t *dst = reinterpret_cast<f4v_t *>(smem);
+        constexpr int NV = L::XB / 16, NK = (NV + 511) / 512;
+        f4v_t tv[NK];
+#pragma unroll
+        for (int k = 0; k < NK; k++)
+            if ((int)threadIdx.x + 512 * k < NV)
+                tv[k] = src[threadIdx.x + 512 * k];
+#pragma unroll
+        for (int k = 0; k < NK; k++)
+            if ((int)threadIdx.x + 512 * k < NV)
+                dst[threadIdx.x + 512 * k] = tv[k];
+        if (threadIdx.x < Q_RING)
+            reinterpret_cast<unsigned long long *>(smem + L::Q + 16)[threadIdx.x] = queue_ring_init(threadIdx.x, blockIdx.x, gridDim.x);
+        if (threadIdx.x < 4)
+            reinterpret_cast<unsigned int *>(smem + L::QCLAIM)[threadIdx.x] = 0u;
+        if (threadIdx.x == 0)
+        {
+            *reinterpret_cast<unsigned long long *>(smem + L::Q) = queue_cur_init(blockIdx.x, gridDim.x, false);
+            *reinterpret_cast<unsigned long long *>(smem + L::QTAIL) = 0ull;
+            if (blockIdx.x == 0)
+            {
+                queue[qsel ^ 1u] = 0u;
+                queue[2u + (qsel ^ 1u)] = 0u;
+            }
+        }
+    }
+    __syncthreads();
+    DevQueue dq{smem + L::Q, smem + L::QTAIL, smem + L::QCLAIM, queue + qsel, queue + 2 + qsel, queue + 4, lane};
+    const unsigned simd = (unsigned)wid & 3u;
+    // the next call's history (as in fir_fft_kernel): the last HL samples of (history || input), one wave
+    if (hist_out && blockIdx.x == 0 && wid == 0)
+    {
+        const int64_t keep = (int64_t)HL;
+        for (int64_t i = lane; i < keep; i += 64)
+        {
+            const int64_t gi = N - keep + i, hi = keep + gi;
+            if constexpr (I16)
+            {
+                const int *src = reinterpret_cast<const int *>(in_), *hsrc = reinterpret_cast<const int *>(hist);
+                reinterpret_cast<int *>(hist_out)[i] = gi >= 0 ? src[gi] : (hi >= 0 ? hsrc[hi] : 0);
+            }
+            else
+                reinterpret_cast<f2v *>(hist_out)[i] = gi >= 0 ? in_[gi] : (hi >= 0 ? hist[hi] : (f2v){0.f, 0.f});
+        }
+    }
+    const f2v *gtab = reinterpret_cast<const f2v *>(smem + ODD_LDS_G);
+    const f2v *tb = reinterpret_cast<const f2v *>(smem + L::TB);
+    const f2v *tc = reinterpret_cast<const f2v *>(smem + L::TC);
+    const f2v *twd = reinterpret_cast<const f2v *>(smem + L::TWD);
+    const f2v *twe = reinterpret_cast<const f2v *>(smem + L::TWE);
+    const f2v *ncob = reinterpret_cast<const f2v *>(smem + L::NCO);
+    (void)ncob;
+    char *xb = smem + L::XB + wid * XBUF;
+    cf x[F][16]; // x[p][row]: sample F (64 row + lane) + p of the block (int16 input: the raw pair in .x until it is used)
+    // row loads of one phase: 8 (4) bytes per lane, F x 8 bytes apart -- the F loads of a row cover one contiguous piece
+    auto load_phase = [&](srd_t srd, int p) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const unsigned vo = ((unsigned)lane * F + (unsigned)p) * ISZ, so = (unsigned)(r * 64 * F * ISZ);
+            if constexpr (I16)
+                x[p][r].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, vo, so, IF_FIR_FFT_LOAD_AUX(0)));
+            else
+                x[p][r] = buf_load<IF_FIR_FFT_LOAD_AUX(0)>(srd, vo, so);
+        }
+    };
+    int64_t blk = queue_take(dq, simd, nblocks, nblocks);
+    bool loaded = false;
+    const unsigned voff = (unsigned)lane * 8u;
+    while (blk < nblocks)
+    {
+        const int64_t s0 = blk * LIN - OVL + n0;
+        if (!loaded && !(diag & 1))
+        {
+            if (s0 >= 0)
+            {
+                const srd_t srd = make_srd(in + s0 * ISZ, (N - s0) * ISZ);
+#pragma unroll
+                for (int p = 0; p < F; p++)
+                    load_phase(srd, p);
+            }
+            else
+            {
+                // first block of a call: negative stream indices come from the history (or are zero)
+                const srd_t srd_in = make_srd(in, N * ISZ);
+                const srd_t srd_h = make_srd(hist, (int64_t)HL * ISZ);
+#pragma unroll
+                for (int p = 0; p < F; p++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                    {
+                        const int64_t gidx = s0 + (int64_t)F * (64 * r + lane) + p, hidx = gidx + HL;
+                        const unsigned oi = (gidx >= 0) ? (unsigned)gidx * (unsigned)ISZ : 0x80000000u;
+                        const unsigned oh = (gidx < 0 && hidx >= 0) ? (unsigned)hidx * (unsigned)ISZ : 0x80000000u;
+                        if constexpr (I16)
+                            x[p][r].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd_in, oi, 0, 0) |
+                                                        __builtin_amdgcn_raw_buffer_load_b32(srd_h, oh, 0, 0));
+                        else
+                            x[p][r] = buf_load(srd_in, oi, 0) + buf_load(srd_h, oh, 0);
+                    }
+            }
+        }
+        int64_t blk_next = nblocks;
+        bool next_fast = false;
+        srd_t nsrd = make_srd(in, 0);
+        cf zacc[16];
+#pragma unroll
+        for (int p = 0; p < F; p++)
+        {
+            cf v[16], z[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = I16 ? cvt_i16(__float_as_uint(x[p][r].x)) : x[p][r];
+            forward_1024_tan(v, z, tb, tc, xb, lane);
+#pragma unroll
+            for (int sidx = 0; sidx < 16; sidx++)
+            {
+                const cf gw = gtab[(p * 16 + sidx) * 64 + lane];
+                zacc[sidx] = p == 0 ? cmul_v<false>(z[sidx], gw) : cmac_v(zacc[sidx], z[sidx], gw);
+            }
+            if (p == 0)
+            {
+                // the next block is taken here: this block's rows have all landed, none of the next one's is in flight
+                blk_next = queue_take(dq, simd, nblocks, nblocks);
+                const int64_t s0n = blk_next * LIN - OVL + n0;
+                next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
+                nsrd = make_srd(in + (next_fast ? s0n : 0) * ISZ, next_fast ? (N - s0n) * ISZ : 0);
+            }
+            // this phase's 16 registers are dead: refill them with the next block's (the float32 instantiation with NCO and thinning
+            // issues the last phase's loads behind the inverse: its store path's index arithmetic would otherwise spill)
+            if (next_fast && !(LATE_LAST && p == F - 1))
+                load_phase(nsrd, p);
+        }
+        cf c[16];
+        inverse_dec4_tan(zacc, c, twe, twd, xb, lane);
+        if (LATE_LAST && next_fast)
+            load_phase(nsrd, F - 1);
+        const int64_t obase = blk * LOUT;
+        // SPEC 3.2: output m = obase + 64 (mu0 - OVLR) + lane of the fs/F-rate tail is rotated by phasor(phi0 + delta m) = A(lane) B(row)
+        cf a_lane = {1.0f, 0.0f};
+        if constexpr (NCO)
+        {
+            const float2 pa = nco_phasor(nco_phi0 + nco_delta * ((uint32_t)obase + (uint32_t)lane));
+            a_lane = (cf){pa.x, pa.y};
+        }
+        (void)a_lane;
+        if constexpr (SUB)
+        {
+            KeepEvery ke;
+            ke.init(blk, (unsigned)LOUT, sub);
+            const int64_t qb = ke.qU + (ke.rem ? 1 : 0);
+            const srd_t dsrd = make_srd(out + qb, (diag & 2) ? 0 : (decn_m - qb) * 8);
+            const int lim = (int)((M - obase) < 65536 ? (M - obase) : 65536);
+            int off = lane;
+#pragma unroll
+            for (int mu0 = OVLR; mu0 < 16; mu0++)
+            {
+                // (one running offset, made opaque: otherwise the store offsets are all computed ahead of the inverse and spill)
+                asm volatile("" : "+v"(off));
+                const int64_t kept = ke.index((unsigned)off);
+                const unsigned so = (kept >= 0 && off < lim) ? (unsigned)(kept - qb) * 8u : 0xffffffffu;
+                cf v = c[mu0];
+                if constexpr (NCO)
+                    v = cmul_v<false>(v, cmul_v<false>(a_lane, ncob[mu0 - OVLR]));
+                buf_store(dsrd, so, 0, v);
+                off += 64;
+            }
+        }
+        else
+        {
+            const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
+#pragma unroll
+            for (int mu0 = OVLR; mu0 < 16; mu0++)
+            {
+                cf v = c[mu0];
+                if constexpr (NCO)
+                    v = cmul_v<false>(v, cmul_v<false>(a_lane, ncob[mu0 - OVLR]));
+                buf_store(osrd, voff, (mu0 - OVLR) * 512, v);
+            }
+        }
+        loaded = next_fast;
+        blk = blk_next;
+    }
+}
+
+template <int F, int OVLR, bool I16, bool NCO, bool SUB>
+static hipError_t launch_odd_t(const LaunchArgs &a, int sub)
+{
+    auto kern = fir_odd_kernel<F, OVLR, I16, NCO, SUB>;
+    constexpr int LOUT = 1024 - 64 * OVLR;
+    static DeviceSetup setup;
+    int ncus = 0;
+    {
+        const hipError_t e = device_setup(setup, a.device, reinterpret_cast<const void *>(kern), OddLds<F>::BYTES, &ncus);
+        if (e != hipSuccess)
+            return e;
+    }
+    const int64_t m_rate = (a.M - 1) * (int64_t)sub + 1; // outputs of the fs/F-rate tail that the call's outputs need
+    const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
+    if (nblocks <= 0)
+        return hipSuccess;
+    const int64_t wgs_max = (a.grid_limit > 0 && a.grid_limit < ncus) ? a.grid_limit : ncus;
+    FftSchedule sch;
+    fft_schedule(nblocks, wgs_max, sch);
+    uint32_t qsel = 0;
+    if (a.queue_base && a.queue_valid && *a.queue_valid)
+        qsel = *a.queue_base & 1u;
+    else
+    {
+        hipError_t e = hipMemsetAsync(a.queue, 0, 16, a.stream);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (a.queue_base && a.queue_valid)
+    {
+        *a.queue_base = qsel ^ 1u;
+        *a.queue_valid = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)sch.wgs), dim3(512), OddLds<F>::BYTES, a.stream, reinterpret_cast<const f2v *>(a.in),
+                       reinterpret_cast<f2v *>(a.out), reinterpret_cast<const f2v *>(a.fft_tables),
+                       reinterpret_cast<const f2v *>(a.hist_full), a.hist_len, a.N, (int32_t)a.n0, m_rate, nblocks, (unsigned int *)a.queue,
+                       (int32_t)a.diag, nco_phi0(a), 0u - a.nco_word * (uint32_t)F, qsel, a.hist_out, (uint32_t)sub, a.M);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess && a.queue_valid)
+        *a.queue_valid = false;
+    return le;
+}
+
+hipError_t launch_fft_odd(const LaunchArgs &a)
+{
+    int F = 1, sub = 1, ovlr = 0;
+    if (!fft_odd_tail(a.T, a.D, &F, &sub, &ovlr) || a.chan || !a.fft_tables)
+        return hipErrorInvalidConfiguration;
+    const int key = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
+#define IF_FIR_ODD_SWITCH(F_, R_)                                                                                         \
+    if (F == F_ && ovlr == R_)                                                                                            \
+    {                                                                                                                     \
+        if (sub == 1)                                                                                                     \
+            switch (key)                                                                                                  \
+            {                                                                                                             \
+            case 0: return launch_odd_t<F_, R_, false, false, false>(a, sub);                                             \
+            case 1: return launch_odd_t<F_, R_, false, true, false>(a, sub);                                              \
+            case 2: return launch_odd_t<F_, R_, true, false, false>(a, sub);                                              \
+            default: return launch_odd_t<F_, R_, true, true, false>(a, sub);                                              \
+            }                                                                                                             \
+        switch (key)                                                                                                      \
+        {                                                                                                                 \
+        case 0: return launch_odd_t<F_, R_, false, false, true>(a, sub);                                                  \
+        case 1: return launch_odd_t<F_, R_, false, true, true>(a, sub);                                                   \
+        case 2: return launch_odd_t<F_, R_, true, false, true>(a, sub);                                                   \
+        default: return launch_odd_t<F_, R_, true, true, true>(a, sub);                                                   \
+        }                                                                                                                 \
+    }
+    IF_FIR_ODD_SWITCH(3, 2)
+    IF_FIR_ODD_SWITCH(3, 4)
+    IF_FIR_ODD_SWITCH(3, 8)
+#undef IF_FIR_ODD_SWITCH
+    return hipErrorInvalidConfiguration;
+}
+#endif // IF_FIR_FFT_ODD
+
 #ifdef IF_FIR_FFT_ROWS // ================= kernel + launcher: the per-overlap-length compilation units =================
 template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, int CHAN, bool DECN, bool ACC>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
@@ -773,7 +1119,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         }
     }
     __syncthreads();
-    DevQueue dq{smem, queue + qsel, queue + 2 + qsel, queue + 4, lane};
+    DevQueue dq{smem + LDS_Q, smem + LDS_QTAIL, smem + LDS_QCLAIM, queue + qsel, queue + 2 + qsel, queue + 4, lane};
     const unsigned simd = (unsigned)wid & 3u; // waves w and w + 4 of a workgroup share a SIMD
     if (plain_start && wid == 0)
         queue_start(dq); // the fetch the (static) slot 0 of local group 0 owes
@@ -1251,7 +1597,84 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 }
             constexpr int MU0_FIRST = OVL_ROWS / 4;
             const int nch = (int)chan.count;
-            static_assert(!NCO, "decimation 8: one instantiation; the context's NCO is part of the channels' mix-down words");
+            if constexpr (!NCO)
+            {
+            // ---- channels on the fs/16 slot grid, no NCO on the context (round 3's form: slot twiddles in SGPRs, the mix-down a sign)
+            for (int cp = 0; cp < nch; cp += 2)
+            {
+                const bool last = cp + 2 >= nch; // the w values die with the last pair: refill with the next block
+                cf a[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++)
+                    {
+                        if (ch == 1 && cp + 1 >= nch) // odd count: an empty second half
+                        {
+                            a[4 * i + 2] = (cf){0.f, 0.f};
+                            a[4 * i + 3] = (cf){0.f, 0.f};
+                            continue;
+                        }
+                        const int c = cp + ch;
+                        const int par = (int)chan.slot[c] & 1;
+                        const f2v *g0 = hp + (i * 16 + 8 * par) * 64 + lane;       // k2' = 0: q = s & 1       (+ a * 64 entries)
+                        const f2v *g1 = hp + (i * 16 + 8 * (1 - par)) * 64 + lane; // k2' = 1: q = (1 - s) & 1
+                        cf z0 = cmul_v<false>(r[phys(i, 0)], g0[0]);
+                        cf z1 = cmul_v<false>(r[phys(i, 8)], g1[0]);
+#pragma unroll
+                        for (int a8 = 1; a8 < 8; a8++)
+                        {
+                            const cf tw = {chan.tw[c][2 * (a8 - 1)], chan.tw[c][2 * (a8 - 1) + 1]};
+                            z0 = cmac_v(z0, cmul_s<false>(r[phys(i, a8)], tw), g0[a8 * 64]);
+                            z1 = cmac_v(z1, cmul_s<false>(r[phys(i, a8 + 8)], tw), g1[a8 * 64]);
+                        }
+                        a[4 * i + 2 * ch] = z0 + z1;
+                        a[4 * i + 2 * ch + 1] = cmul_v<true>(z0 - z1, twd[(i * 4 + 2) * 64 + lane]); // conj W512^(16 k1 + k0)
+                    }
+                    if (last && i < EARLY_GROUPS && next_fast)
+                    {
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
+                    }
+                }
+                cf c[16];
+                inverse_tail256(a, c, twe, xb, lane);
+                if (last && next_fast)
+                {
+#pragma unroll
+                    for (int i = EARLY_GROUPS; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
+                }
+                // mix-down: exp(-j 2 pi s a / 16), a = abs0 + n0 + 8 m: the call constant rot0 times (-1)^(s m); m = obase +
+                // 32 (mu0 - first) + 2 mu1 + mu2 with obase even, so the sign is (-1)^(s mu2)
+                const int chl = (lane >> 1) & 1, cl = cp + chl;
+                const int c1 = (cp + 1 < nch) ? cp + 1 : nch - 1;
+                float2 *po = chl ? chan.out[c1] : chan.out[cp];
+                const cf r0 = chl ? (cf){chan.rot0[c1][0], chan.rot0[c1][1]} : (cf){chan.rot0[cp][0], chan.rot0[cp][1]};
+                const int sl = chl ? (int)chan.slot[c1] : (int)chan.slot[cp];
+                cf wl = ((sl & lane) & 1) ? (cf){-r0.x, -r0.y} : r0;
+                const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
+                if (cl < nch && !(diag & 2))
+                {
+#pragma unroll
+                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    {
+                        const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
+                        if (idx < M)
+                        {
+                            __builtin_nontemporal_store(cmul_v<false>(c[mu0], wl), reinterpret_cast<cf *>(po) + idx);
+                        }
+                    }
+                }
+            }
+            }
+            else
+            {
+            // ---- general form (template flag NCO): channels at any centre bin and / or an NCO on the context
             // Round 4: every channel has its own centre bin B = 256 s + b (the prototype moved up by B / 4096 cycles/sample: b = 0
             // is round 3's slot grid).  H_c(k) = H(k - B): with k = k_low + 256 k2 (k_low = k0 + 16 k1 < 256 held by this lane and
             // group) k_low - b = kappa - 256 cy, so the lane needs the table entries of low index kappa -- group (i - b) mod 4, the
@@ -1341,6 +1764,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         }
                     }
                 }
+            }
             }
         }
         else if constexpr (CHAN == 4)
@@ -1667,7 +2091,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 }
 
 #endif // IF_FIR_FFT_ROWS
-#ifndef IF_FIR_FFT_ROWS // ================= host side =================
+#ifdef IF_FIR_FFT_HOST // ================= host side =================
 // Host view of the block queue (see queue_take): groups of FFT_WAVES blocks in global order; workgroup b starts with
 // global group b (static), every further group of a workgroup is global group wgs + ticket.  Tickets keep being drawn
 // past the end (a wave learns that it is done by receiving a block >= nblocks), at most one per group slot 0 taken, so a
@@ -1751,7 +2175,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 }
 
 #endif // IF_FIR_FFT_ROWS
-#ifndef IF_FIR_FFT_ROWS
+#ifdef IF_FIR_FFT_HOST
 // D = 1 and D = 4 have their own kernels; any other decimation runs the full-rate kernel with a selecting store.
 // Taps: the first T-1 outputs of a 4096-point block are discarded, in whole 64-sample rows (4, 8, 16, 32 or 48 of the
 // 64): up to 257 taps cost 6 % of the block, 513 taps 12.5 %, 1025 taps 25 %, 2049 taps half, 3073 taps three quarters.
@@ -1785,16 +2209,41 @@ bool fft_two_partitions(int T)
     return T > 3073;
 }
 
-// Overlap rows of the (taps, decimation) pair.  Round 4 built a 2-row kernel (L = 3968) for filters of at most 129 taps on the
-// full-rate pipeline (D = 1 and the odd decimations): 2^26 samples are then 16 913 blocks instead of 17 477.  Measured on BASELINE
-// configs[1] it is 3 % SLOWER than the 4-row kernel (profiles/r04_two_row_overlap.txt), so the default stays 4 rows
-// (IF_FIR_FFT_SHORT_ROWS) and the 2-row unit is a development variant.
+// Odd decimations divisible by 3 or 5 (round 4, fir_odd_kernel): D = F sub; a block of F x 1024 input samples gives 1024 outputs
+// at the fs/F rate, the first ceil((T - 1 + F - 1) / F) of which are invalid -- dropped as 2, 4 or 8 rows of 64.
+bool fft_odd_tail(int T, int D, int *pF, int *pSub, int *pOvlr)
+{
+    int F = 1, ovlr = 0;
+    if (D >= 3 && D <= 64 && (D & 1) && T >= 1 && !fft_two_partitions(T))
+    {
+        // (F = 5 -- decimation 5, 25, 35, 55 -- was written and dropped: five phase streams of 16 registers + the transforms'
+        // temporaries do not fit 256 VGPRs, the compiler spilled 112 of them; those decimations keep the selecting store)
+        F = (D % 3 == 0) ? 3 : 1;
+        if (F > 1)
+        {
+            const int need = (T - 1 + F - 1 + F - 1) / F; // outputs of a block that see samples ahead of it
+            ovlr = need <= 128 ? 2 : need <= 256 ? 4 : need <= 512 ? 8 : 0;
+            if (!ovlr)
+                F = 1;
+        }
+    }
+    if (pF)
+        *pF = F;
+    if (pSub)
+        *pSub = F > 1 ? D / F : 1;
+    if (pOvlr)
+        *pOvlr = ovlr;
+    return F > 1;
+}
+
+// Overlap rows of the (taps, decimation) pair.  (Round 4 built and measured a 2-row kernel, L = 3968, for filters of at most 129
+// taps on the full-rate pipeline -- 16 913 instead of 17 477 blocks for BASELINE configs[1]: within 1 % of the 4-row kernel on a
+// stream that is not re-read from the memory-side cache, profiles/r04_two_row_overlap.txt -- and removed it again.)
 int fft_overlap_rows(int T, int D)
 {
     if (fft_two_partitions(T))
         return 32; // each partition runs the 32-row kernel
-    if (IF_FIR_FFT_SHORT_ROWS == 2 && T - 1 <= 128 && !fft_tail(T, D, nullptr, nullptr))
-        return 2;
+    (void)D;
     return (T - 1 <= 256) ? 4 : (T - 1 <= 512) ? 8 : (T - 1 <= 1024) ? 16 : (T - 1 <= 2048) ? 32 : 48;
 }
 
@@ -1802,6 +2251,9 @@ int fft_overlap_rows(int T, int D)
 // decimation) give bit-identical results to the unsplit stream (the multi-channel front's chunk unit)
 int fft_block_advance(int T, int D)
 {
+    int F = 1, ovlr = 0;
+    if (fft_odd_tail(T, D, &F, nullptr, &ovlr))
+        return F * (1024 - 64 * ovlr);
     return fft_two_partitions(T) ? FFT_N - FFT_PART : FFT_N - 64 * fft_overlap_rows(T, D);
 }
 
@@ -1825,8 +2277,21 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             (a.D == 4 && (a.nco_word || a.ctaps)))
             return hipErrorInvalidConfiguration;
         const int ckey = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
-        if (a.D == 8) // per channel (pairs share a small inverse); chan->bin[] / pword[]: centre bin and mix-down word of a channel
-            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 8>(a) : launch_fft_t<ROWS, true, false, false, 8>(a);
+        if (a.D == 8) // per channel (pairs share a small inverse)
+        {
+            // slot form (chan->tw[] = W16^(a slot), a = 1..7) when every channel sits on the fs/16 grid and the context has no NCO;
+            // the general form (chan->bin[] / pword[]: centre bin and mix-down word of a channel) otherwise
+            bool general = a.nco_word != 0;
+            for (uint32_t c = 0; c < a.chan->count; c++)
+                general = general || (a.chan->bin[c] & 255u) || a.chan->pword[c] != (a.chan->bin[c] << 20);
+            switch ((a.in_i16 ? 2 : 0) | (general ? 1 : 0))
+            {
+            case 0: return launch_fft_t<ROWS, true, false, false, 8>(a);
+            case 1: return launch_fft_t<ROWS, true, false, true, 8>(a);
+            case 2: return launch_fft_t<ROWS, true, true, false, 8>(a);
+            default: return launch_fft_t<ROWS, true, true, true, 8>(a);
+            }
+        }
         if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
             switch (ckey)
             {
@@ -1947,22 +2412,18 @@ hipError_t launch_fft_two_partitions(const LaunchArgs &a)
 #endif // 32-row unit
 #endif // IF_FIR_FFT_ROWS
 
-#ifndef IF_FIR_FFT_ROWS
+#ifdef IF_FIR_FFT_HOST
 hipError_t launch_fft(const LaunchArgs &a)
 {
     if (!fft_supported(a.T, a.D) || !a.fft_tables)
         return hipErrorInvalidConfiguration;
+    if (!a.chan && !a.no_fold && fft_odd_tail(a.T, a.D, nullptr, nullptr, nullptr))
+        return launch_fft_odd(a);
     if (fft_two_partitions(a.T))
         return launch_fft_two_partitions(a);
-    // (the filter bank's decimations are even: never 2 rows)
-    int rows = fft_overlap_rows(a.T, a.D);
-    // development (A/B runs), diag 1024: filters of at most 129 taps on the full-rate pipeline take the other of the two block
-    // lengths (2 <-> 4 overlap rows)
-    if ((a.diag & 1024) && a.T - 1 <= 128 && !fft_tail(a.T, a.D, nullptr, nullptr) && !a.chan)
-        rows = rows == 2 ? 4 : 2;
+    const int rows = fft_overlap_rows(a.T, a.D);
     switch (rows)
     {
-    case 2: return launch_fft_rows<2>(a);
     case 4: return launch_fft_rows<4>(a);
     case 8: return launch_fft_rows<8>(a);
     case 16: return launch_fft_rows<16>(a);
@@ -2200,6 +2661,82 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
     for (int mu2 = 0; mu2 < 4; mu2++) // inverse, middle pass: b = W64^mu2
         tan_fft16_entries(-PI2 * (double)mu2 / 64.0, twe + 2 * mu2, 4);
 #endif
+}
+
+// Table image of the odd-decimation kernel (fir_odd_kernel, F = 3 or 5), float64 math, rounded once:
+//   G_p [(p*16 + slot)*64 + lane] = FFT1024(g_p)[k0 + 16 k1 + 256 k2'] / 1024 (slot = 4 i + k2', k0 = 4 (lane/16) + i, k1 = lane%16),
+//        g_0[k] = h[F k], g_p[d] = h[F d - p] (p >= 1, d >= 1);  in_scale: 2^-15 for raw int16 samples
+//   TB [e*16 + k0] (b = W256^k0) | TC [(i*3 + e)*64 + lane] (b = W1024^(k0 + 16 k1), entries 0..2 of the transform's 15)
+//   TWD [e*64 + lane] (b = W1024^lane) | TWE [e*4 + mu2] (b = W64^mu2) | NCO row phasors (64 outputs per row)
+void fft_build_tables_odd(const float *taps, int T, int ctaps, int F, uint32_t nco_delta, double in_scale, float *tables)
+{
+    const double PI2 = 6.283185307179586476925286766559;
+    float *gt = tables, *tb = gt + 2 * F * 1024, *tc = tb + 2 * 256, *twd = tc + 2 * 768, *twe = twd + 2 * 1024, *ncob = twe + 2 * 64;
+    for (int e = 0; e < 2 * (256 + 768 + 1024 + 64 + 64); e++)
+        tb[e] = 0.0f;
+    for (int k0 = 0; k0 < 16; k0++)
+        tan_fft16_entries(-PI2 * (double)k0 / 256.0, tb + 2 * k0, 16);
+    for (int i = 0; i < 4; i++)
+        for (int lane = 0; lane < 64; lane++)
+        {
+            float all[30];
+            tan_fft16_entries(-PI2 * (double)((4 * (lane / 16) + i) + 16 * (lane % 16)) / 1024.0, all, 1);
+            // (the last pass is a 4-point DFT over mu2: its inputs carry b, b^2, b^3 = entries 3, 4, 5 of the 16-point set, q = 0)
+            for (int e = 0; e < 3; e++)
+            {
+                tc[2 * ((i * 3 + e) * 64 + lane) + 0] = all[2 * (3 + e)];
+                tc[2 * ((i * 3 + e) * 64 + lane) + 1] = all[2 * (3 + e) + 1];
+            }
+        }
+    for (int lane = 0; lane < 64; lane++)
+        tan_fft16_entries(-PI2 * (double)lane / 1024.0, twd + 2 * lane, 64);
+    for (int mu2 = 0; mu2 < 4; mu2++)
+        tan_fft16_entries(-PI2 * (double)mu2 / 64.0, twe + 2 * mu2, 4);
+    for (uint32_t r = 0; r < 64; r++)
+    {
+        const double a = PI2 * ((double)(uint32_t)(64u * r * nco_delta) / 4294967296.0);
+        ncob[2 * r + 0] = (float)cos(a);
+        ncob[2 * r + 1] = (float)sin(a);
+    }
+    std::vector<double> ct(1024), st(1024), gr(1024), gi(1024);
+    for (int e = 0; e < 1024; e++)
+    {
+        ct[e] = cos(-PI2 * (double)e / 1024.0);
+        st[e] = sin(-PI2 * (double)e / 1024.0);
+    }
+    for (int p = 0; p < F; p++)
+    {
+        // polyphase component p at the decimated rate, with the delay of its phase stream
+        for (int e = 0; e < 1024; e++)
+            gr[e] = gi[e] = 0.0;
+        for (int k = 0; k < T; k++)
+        {
+            // x[F m - k] = x_p[m - d] with F d - p = k
+            if ((k + p) % F)
+                continue;
+            const int d = (k + p) / F;
+            gr[d] += ctaps ? (double)taps[2 * k] : (double)taps[k];
+            gi[d] += ctaps ? (double)taps[2 * k + 1] : 0.0;
+        }
+        int dmax = 0;
+        for (int e = 0; e < 1024; e++)
+            if (gr[e] != 0.0 || gi[e] != 0.0)
+                dmax = e;
+        for (int slot = 0; slot < 16; slot++)
+            for (int lane = 0; lane < 64; lane++)
+            {
+                const int k = (4 * (lane / 16) + slot / 4) + 16 * (lane % 16) + 256 * (slot % 4);
+                double re = 0.0, im = 0.0;
+                for (int d = 0; d <= dmax; d++)
+                {
+                    const int e = (int)(((int64_t)k * d) & 1023);
+                    re += gr[d] * ct[e] - gi[d] * st[e];
+                    im += gr[d] * st[e] + gi[d] * ct[e];
+                }
+                gt[2 * ((p * 16 + slot) * 64 + lane) + 0] = (float)(re / 1024.0 * in_scale);
+                gt[2 * ((p * 16 + slot) * 64 + lane) + 1] = (float)(im / 1024.0 * in_scale);
+            }
+    }
 }
 
 #endif // host side

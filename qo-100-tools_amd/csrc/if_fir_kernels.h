@@ -135,6 +135,13 @@ hipError_t launch_fft(const LaunchArgs &a);
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale, float *tables,
                       int bank = 0);
 
+// Odd decimations F x sub, F = 3 or 5 (round 4): blocks of F x 1024 input samples, F forward 1024-point transforms of the phase
+// streams and one inverse (fir_odd_kernel); *pOvlr = dropped 64-output rows of a block (2, 4 or 8).  False: no such tail (the
+// full-rate pipeline + selecting store serves the pair).
+bool fft_odd_tail(int T, int D, int *pF, int *pSub, int *pOvlr);
+constexpr int fft_odd_table_floats(int F) { return 2 * (F * 1024 + 256 + 768 + 1024 + 64 + 64); } // G_p | TB | TC | TWD | TWE | NCO
+void fft_build_tables_odd(const float *taps, int T, int ctaps, int F, uint32_t nco_delta, double in_scale, float *tables);
+hipError_t launch_fft_odd(const LaunchArgs &a);
 int fft_overlap_rows(int T, int D);
 int fft_block_advance(int T, int D); // new input samples per block: the unit at which a stream can be cut without changing a bit
 // decimating tail of (T, D): D = F * sub, F = 2 or 4 the tail's own decimation (false, F = 1: full-rate kernel + selecting store)

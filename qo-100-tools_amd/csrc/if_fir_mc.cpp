@@ -105,6 +105,7 @@ constexpr uint64_t MC_CHUNK_DEFAULT = 16773120; // 78 x 215 040 (round 3's globa
 namespace if_fir
 {
 bool fft_tail(int T, int D, int *pF, int *pSub); // if_fir_fft.hip
+bool fft_odd_tail(int T, int D, int *pF, int *pSub, int *pOvlr);
 int fft_block_advance(int T, int D);
 }
 // internal to the library (if_fir_shim.cpp, hidden): device address of the context's queue fault counter
@@ -504,7 +505,9 @@ static uint64_t mc_gcd(uint64_t a, uint64_t b)
 // stream position is off-phase); every other kernel anchors it at the call's first sample.
 static bool mc_grid_follows_phase(uint32_t taps, uint32_t decim)
 {
-    return if_fir::fft_tail((int)taps, (int)decim, nullptr, nullptr);
+    // (round 4: the odd-decimation kernel -- decimation 3, 9, 15, ... -- anchors its blocks at the first output as well)
+    return if_fir::fft_tail((int)taps, (int)decim, nullptr, nullptr) ||
+           if_fir::fft_odd_tail((int)taps, (int)decim, nullptr, nullptr, nullptr);
 }
 
 // The unit of a context's chunks: lcm(block advance of its filter, 2 D).  Every chunk then produces an even number of outputs

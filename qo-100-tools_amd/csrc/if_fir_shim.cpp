@@ -44,6 +44,7 @@ struct if_fir_ctx
     uint32_t chunk_ev_count;
     float tone[10];
     float *h_taps; // host copy of the caller's taps (FFT tables are built on demand)
+    bool tables_odd;   // d_fft_tables holds the odd-decimation kernel's image (ensure_fft_tables)
     uint32_t nco_word; // SPEC §3.2 phase word (0 = no NCO)
     float *h_eff; // NCO on: effective complex taps g[k] = h[k] e^{+j theta k} (2T floats), else nullptr
     void *d_fft_tables; // overlap-save backend tables (built on first use)
@@ -113,14 +114,17 @@ static uint32_t resolve_backend(const if_fir_ctx *ctx, uint32_t req)
 // overlap (4..48 rows of 64 samples) before their first output, and keeping that many makes the first block of a call
 // identical to the interior block an unsplit call would have had there (results independent of how a stream is cut
 // into calls, as long as the cuts are multiples of the block advance: if_fir_mc_set_chunk_samples).
-static int hist_len_for(int T)
+static int hist_len_for(int T, int D)
 {
     const int need = T > 1 ? T - 1 : 0;
     if (!if_fir::fft_supported(T, 1))
         return need;
     if (if_fir::fft_two_partitions(T))
         return 4096; // second partition: 2048 samples of delay + the 2048-sample block overlap
-    const int ovl = 64 * if_fir::fft_overlap_rows(T, 4); // (the longest overlap any decimation of this filter uses)
+    int ovl = 64 * if_fir::fft_overlap_rows(T, 4); // (the longest overlap any decimation of this filter uses)
+    int F = 1, ovlr = 0;
+    if (if_fir::fft_odd_tail(T, D, &F, nullptr, &ovlr) && F * 64 * ovlr > ovl)
+        ovl = F * 64 * ovlr; // the odd-decimation kernel's blocks (F x 1024 samples) overlap by F x 64 x ovlr input samples
     return ovl > need ? ovl : need;
 }
 
@@ -157,13 +161,18 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
         return 1;
     // 3074..4096 taps run as two partitions (2048 taps + the rest): two table images back to back
     const bool two = if_fir::fft_two_partitions(ctx->T);
-    const size_t tab_floats = (size_t)if_fir::FFT_TABLE_FLOATS * (two ? 2 : 1);
+    // odd decimations 3, 9, 15, ... (round 4): the image of fir_odd_kernel (development variant 3000 = the full-rate pipeline with
+    // a selecting store instead, on the ordinary image; if_fir_set_tuning drops the tables when it crosses that line)
+    int oddF = 1;
+    const bool odd = if_fir::fft_odd_tail(ctx->T, ctx->D, &oddF, nullptr, nullptr) && ctx->variant != 3000;
+    const size_t tab_floats = odd ? (size_t)if_fir::fft_odd_table_floats(oddF) : (size_t)if_fir::FFT_TABLE_FLOATS * (two ? 2 : 1);
     float *tab = (float *)malloc(sizeof(float) * tab_floats);
     if (!tab)
     {
         set_err(ctx, "overlap-save tables: out of host memory");
         return 0;
     }
+    ctx->tables_odd = odd;
     // NCO row phasors: per kept output for the decimate-by-4 kernel, per full-rate output for all others
     // int16 input: the kernel leaves the samples unscaled and the table carries the format's 2^-15
     // decimation 4 and its multiples (8, 12, ..., 64: the same tail keeping every sub-th output) take the merged table and
@@ -171,7 +180,10 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
     const int F = tail_factor(ctx);
     const int tabD = F == 4 ? 4 : 1;
     const uint32_t tab_nco = 0u - ctx->nco_word * (F == 4 ? 4u : 1u);
-    if (two)
+    if (odd)
+        if_fir::fft_build_tables_odd(eff_taps(ctx), ctx->T, eff_ctaps(ctx), oddF, 0u - ctx->nco_word * (uint32_t)oddF,
+                                     ctx->in_i16 ? 0x1p-15 : 1.0, tab);
+    else if (two)
     {
         // two partitions: each a filter of <= 2048 taps with its own table image
         const int step = eff_ctaps(ctx) ? 2 : 1, part = 2048;
@@ -325,7 +337,7 @@ static uint8_t init_common(if_fir_ctx_t **ppCtx, const float *pfTaps, uint32_t u
     INIT_TRY(hipMemcpy(ctx->d_taps, pfTaps, sizeof(float) * tap_floats, hipMemcpyHostToDevice));
     INIT_TRY(hipMalloc(&ctx->d_queue, 32));
     INIT_TRY(hipMemset(ctx->d_queue, 0, 32));
-    ctx->hist_len = hist_len_for((int)ulTaps);
+    ctx->hist_len = hist_len_for((int)ulTaps, (int)ulDecimation);
     const size_t hist_bytes = 8 * (size_t)(ctx->hist_len > 0 ? ctx->hist_len : 1);
     for (int i = 0; i < 2; i++)
     {
@@ -470,6 +482,15 @@ IF_FIR_API uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant)
         return 0;
     }
 #endif
+    if (((int)ulVariant == 3000) != (pCtx->variant == 3000) && pCtx->d_fft_tables &&
+        if_fir::fft_odd_tail(pCtx->T, pCtx->D, nullptr, nullptr, nullptr))
+    {
+        // the selecting-store route and the odd-decimation kernel take different table images: rebuilt on the next call
+        HIP_TRY(pCtx, hipSetDevice(pCtx->device));
+        HIP_TRY(pCtx, hipStreamSynchronize(pCtx->stream));
+        (void)hipFree(pCtx->d_fft_tables);
+        pCtx->d_fft_tables = nullptr;
+    }
     pCtx->variant = (int)ulVariant;
     return 1;
 }
@@ -943,6 +964,18 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps
         return 0; // (a two-partition filter is two such images, one per partition of <= 2048 taps)
     if_fir::fft_build_tables(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, (int)ulDecimation, ulNcoDelta, 1.0, pfOut);
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
+}
+
+// Host-only: the table image of the odd-decimation kernel (fir_odd_kernel, F = 3) for a set of taps
+IF_FIR_API uint32_t if_fir_debug_fft_tables_odd(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
+                                                uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats)
+{
+    int F = 1;
+    if (!pfTaps || !pfOut || !if_fir::fft_odd_tail((int)ulTaps, (int)ulDecimation, &F, nullptr, nullptr) ||
+        ulOutFloats < (uint32_t)if_fir::fft_odd_table_floats(F))
+        return 0;
+    if_fir::fft_build_tables_odd(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, F, ulNcoDelta, 1.0, pfOut);
+    return (uint32_t)if_fir::fft_odd_table_floats(F);
 }
 
 // bounded waits of the block queue that expired (if_fir_fft_queue.h): word 4 of the queue block

@@ -31,7 +31,7 @@ EXPORTS = [
     "if_fir_mc_set_chunk_samples", "if_fir_mc_get_chunk_samples",
 ]
 # every symbol include/if_fir_debug.h declares: exported by libif_fir_dev.so only
-DEV_EXPORTS = ["if_fir_time_device", "if_fir_debug_stamps", "if_fir_debug_fft_tables", "if_fir_debug_fft_schedule",
+DEV_EXPORTS = ["if_fir_time_device", "if_fir_debug_stamps", "if_fir_debug_fft_tables", "if_fir_debug_fft_tables_odd", "if_fir_debug_fft_schedule",
                "if_fir_mc_debug_plan", "if_fir_debug_queue_faults"]
 MC_ID_BYTES = 128
 
@@ -407,6 +407,23 @@ def debug_fft_tables(taps, decimation, complex_taps=False, nco_delta=0):
     c = out.view(np.complex64)
     return {"tw1": c[0:4096], "hp": c[4096:8192], "tw2": c[8192:8448], "twd": c[8448:9472], "twe": c[9472:10496],
             "ncob": c[10496:10560], "twf": c[10560:10816]}
+
+
+def debug_fft_tables_odd(taps, decimation, complex_taps=False, nco_delta=0):
+    """if_fir_debug_fft_tables_odd(): the odd-decimation kernel's table image (decimation 3, 9, 15, ...) as complex64 sections."""
+    taps = np.ascontiguousarray(taps, dtype=np.float32)
+    t = taps.size // 2 if complex_taps else taps.size
+    nfl = 10496
+    out = np.zeros(nfl, dtype=np.float32)
+    L = dev_lib()
+    L.if_fir_debug_fft_tables_odd.restype = ctypes.c_uint32
+    n = L.if_fir_debug_fft_tables_odd(_f32p(taps), ctypes.c_uint32(t), ctypes.c_uint32(1 if complex_taps else 0),
+                                      ctypes.c_uint32(int(decimation)), ctypes.c_uint32(int(nco_delta) & 0xFFFFFFFF), _f32p(out),
+                                      ctypes.c_uint32(out.size))
+    if n != nfl:
+        raise IfFirError("if_fir_debug_fft_tables_odd: (taps=%d, decimation=%d) is not served by the odd-decimation kernel" % (t, decimation))
+    c = out.view(np.complex64)
+    return {"g": c[0:3072], "tb": c[3072:3328], "tc": c[3328:4096], "twd": c[4096:5120], "twe": c[5120:5184], "ncob": c[5184:5248]}
 
 
 def debug_fft_schedule(nblocks, workgroups=256):

@@ -595,57 +595,6 @@ def test_multi_channel_front_splits_calls_on_the_overlap_save_backend_only(fir, 
             assert l2 <= TOL and mx <= TOL, (fmt, l2, mx)
 
 
-@pytest.mark.parametrize("t,d", [(127, 1), (129, 1), (65, 3), (3, 1), (127, 5), (97, 7), (1, 1)])
-def test_short_filters_on_two_overlap_rows(fir, oracle, t, d):
-    """Round 4 (VERDICT r3 #1a): filters of at most 129 taps on the full-rate pipeline (D = 1, odd D) CAN discard 2 rows of a
-    4096-point block instead of 4 (L = 3968; development variant 1024 -- measured 3 % slower on BASELINE configs[1], so not
-    the default).  The 2-row kernel against the float64 oracle: one call, ragged pieces around its block advance, bit-identical
-    when cut at multiples of it and on a one-workgroup grid, the NCO, int16 input; and the default 4-row kernel beside it."""
-    rng = np.random.default_rng(1000 * t + d)
-    taps = fir.bpf_design(t) if (t % 2 and t >= 3) else np.array([0.75], dtype=np.float32)
-    n = 3968 * 9 + 17
-    x = np.concatenate([oracle.synth_iq(n // 2, 5), rng.standard_normal(2 * (n - n // 2)).astype(np.float32)])
-    xi = rng.integers(-32768, 32768, 2 * n, dtype=np.int16)
-    ref = oracle.fir_f64(taps, x, d)
-    os.environ["IF_FIR_DEBUG"] = "1"
-    try:
-        with fir.IfFir(taps, d, n, dev=True) as f:
-            assert f.get_backend() == fir.BACKEND_HIP_FFT
-            y4 = f.process(x)                    # the default: 4 overlap rows
-            l2, mx = oracle.err_metrics(y4, ref)
-            assert l2 <= TOL and mx <= TOL, ("4 rows", l2, mx)
-            f.reset()
-            f.set_tuning(1000000 + 1024)         # 2 overlap rows
-            y = f.process(x)
-            l2, mx = oracle.err_metrics(y, ref)
-            assert l2 <= TOL and mx <= TOL, (l2, mx)
-            assert t == 1 or not np.array_equal(y, y4)      # (another block grid: the last bits differ)
-            f.reset()
-            cuts = [0, 1, 127, 128, 129, 3967, 3968, 3969, 2 * 3968, 2 * 3968 + 3840, 30_000, n]
-            parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
-            l2, mx = oracle.err_metrics(np.concatenate(parts), ref)
-            assert l2 <= TOL and mx <= TOL, (l2, mx)
-            # cuts at multiples of the block advance (and of D): bit-identical to the unsplit call
-            f.reset()
-            cuts = [0, 3968 * d, 4 * 3968 * d if 4 * 3968 * d < n else n, n]
-            parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
-            assert np.array_equal(np.concatenate(parts), y)
-            # NCO and int16 input through the same instantiations
-            f.reset()
-            f.set_nco(0.1234)
-            yn = f.process(x)
-            l2, mx = oracle.err_metrics(yn, oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(0.1234)))
-            assert l2 <= TOL and mx <= TOL, ("nco", l2, mx)
-        with fir.IfFir(taps, d, n, dev=True) as f:
-            f.set_input_format(fir.INPUT_I16)
-            f.set_tuning(1000000 + 1024)
-            yi = f.process(xi)
-            l2, mx = oracle.err_metrics(yi, oracle.fir_f64(taps, xi.astype(np.float32) * np.float32(2.0 ** -15), d))
-            assert l2 <= TOL and mx <= TOL, ("i16", l2, mx)
-    finally:
-        os.environ.pop("IF_FIR_DEBUG", None)
-
-
 def test_multi_channel_front_loopback_over_the_real_rccl(fir, oracle, torch_cuda):
     """The multi-channel front's whole transfer protocol over the REAL librccl on one GPU (round 3): with IF_FIR_MC_LOOPBACK=N the
     development library lets one process play all ranks of an N-rank world over a one-rank communicator -- every send of
@@ -1141,14 +1090,20 @@ def test_contexts_on_concurrent_threads(fir, oracle):
                                  (3073, 8), (1023, 2), (2047, 2), (3073, 2), (31, 2), (255, 32), (1023, 32), (127, 64), (3073, 64),
                                  (255, 12), (1023, 20), (255, 24), (513, 28), (2047, 40), (255, 48), (3073, 56), (255, 60), (127, 44),
                                  (3073, 12), (255, 6), (3075, 12), (1023, 10), (255, 62), (513, 14), (3073, 30), (3075, 6),
-                                 (4095, 2), (4095, 16), (3333, 4), (4001, 20)])
+                                 (4095, 2), (4095, 16), (3333, 4), (4001, 20),
+                                 # round 4: decimation 3, 9, 15, ... on the odd-decimation kernel (blocks of 3 x 1024 samples; 2, 4 or 8
+                                 # dropped output rows: <= 383 / 767 / 1535 taps), 1537 taps and decimation 5 / 25 on the selecting store
+                                 (255, 9), (383, 3), (385, 3), (767, 15), (769, 3), (1023, 3), (1535, 3), (1537, 3), (255, 21), (255, 63),
+                                 (3, 3), (1, 9), (127, 27), (511, 33), (255, 25), (129, 45)])
 def test_fft_backend_any_decimation(fir, oracle, t, d):
     """Decimations other than 1 and 4 on the overlap-save backend: the full-rate kernel keeps every D-th output (one
     64-bit division per block and lane, an exact multiply-shift per row); decimation 2 (frequency-domain fold + 2048-point
     inverse) and 8 / 16 / 32 / 64 (the one-channel filter-bank route; 32 and 64 keep every 2nd / 4th output of the
     decimate-by-16 tail) have their own tails since round 3 (development variant 3000 = the selecting store for them too); so
     have the multiples of 4 and 8 (12, 20, ..., 60 behind the decimate-by-4 tail, 24, 40, 48, 56 behind the decimate-by-8 one: the
-    tail keeps every 3rd, 5th, ... output), and 6, 10, ..., 62 behind the decimate-by-2 tail: every even decimation has a tail.  One
+    tail keeps every 3rd, 5th, ... output), and 6, 10, ..., 62 behind the decimate-by-2 tail: every even decimation has a tail; round 4:
+    decimation 3, 9, 15, ..., 63 on the odd-decimation kernel (three forward 1024-point transforms of the phase streams, one inverse;
+    variant 3000 = the selecting store with the ordinary tables, rebuilt when the variant changes).  One
     call, ragged pieces (every decimation phase at a call boundary), the run queue on a one-workgroup grid, NCO (always
     the selecting store) and int16 input on top."""
     rng = np.random.default_rng(7000 + t + d)
@@ -1165,7 +1120,7 @@ def test_fft_backend_any_decimation(fir, oracle, t, d):
         for tuning in (0, 2001, 3000):
             f.set_tuning(tuning)
             f.reset()
-            cuts = [0, 1, 2, d, d + 1, 3841, 3842 + d, 50_001, 100_003, n]
+            cuts = [0, 1, 2, d, d + 1, 2688, 2689, 3841, 3842 + d, 50_001, 100_003, n]
             parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
             yp = np.concatenate(parts)
             assert yp.shape == ref.shape
@@ -1190,6 +1145,64 @@ def test_fft_backend_any_decimation(fir, oracle, t, d):
         parts = [f.process(xi[2 * a:2 * b]) for a, b in ((0, 33_333), (33_333, n))]
         l2, mx = oracle.err_metrics(np.concatenate(parts), oracle.fir_f64(taps, xf, d))
         assert l2 <= TOL and mx <= TOL, ("i16", l2, mx)
+
+
+@pytest.mark.parametrize("t,d", [(255, 3), (255, 9), (1023, 3), (511, 15)])
+def test_odd_decimation_kernel_blocks_queue_and_split_invariance(fir, oracle, torch_cuda, t, d):
+    """Round 4: the odd-decimation kernel at sizes that run every stage of its block queue (1.05 M samples on one
+    and three workgroups: bit-identical to the default launch), streams cut at multiples of its block advance (bit-identical to
+    the unsplit call, as for the other tails), complex taps, and the multi-channel front's chunks on its block grid."""
+    torch = torch_cuda
+    n = 1_050_007
+    taps = fir.bpf_design(t)
+    x = oracle.synth_iq(n, 31)
+    ref = oracle.fir_f64(taps, x, d)
+    need = (t - 1 + 2 + 2) // 3
+    adv = 3 * (1024 - 64 * (2 if need <= 128 else 4 if need <= 256 else 8))
+    with fir.IfFir(taps, d, n, dev=True) as f:
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        y0 = f.process(x)
+        l2, mx = oracle.err_metrics(y0, ref)
+        assert l2 <= TOL and mx <= TOL, (l2, mx)
+        for k in (1, 3):
+            f.reset()
+            f.set_tuning(2000 + k)
+            assert np.array_equal(f.process(x), y0), k
+        f.set_tuning(0)
+        f.reset()
+        unit = int(np.lcm(adv, d))
+        cuts = [0, 5 * unit, 5 * unit + 40 * unit, n]
+        parts = [f.process(x[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts), y0)
+        assert f.debug_queue_faults() == 0
+    g = fir.bpf_design_complex(t, 0.2, 0.1)
+    with fir.IfFir(g, d, 200_001, complex_taps=True) as f:
+        xs = x[:2 * 200_001]
+        l2, mx = oracle.err_metrics(f.process(xs), oracle.fir_ctaps_f64(g, xs, d))
+        assert l2 <= TOL and mx <= TOL, ("complex taps", l2, mx)
+    # the multi-channel front cuts its calls on this kernel's block grid: chunked = unchunked bit for bit, off-phase second call
+    tp = np.stack([fir.bpf_design(t, 0.15, 0.25), fir.bpf_design(t, 0.02, 0.08)])
+    dev_in = [torch.from_numpy(oracle.synth_iq(n, 70 + c)).cuda() for c in range(2)]
+    res = {}
+    with fir.IfFirMc(tp, d, n) as mc:
+        for chunk in (fir.MC_NEVER_SPLIT, fir.MC_CHUNK_UNIT):
+            mc.set_chunk_samples(chunk)
+            eff, unit = mc.get_chunk_samples()
+            assert unit == np.lcm(adv, 2 * d)
+            mc.reset()
+            parts = [[], []]
+            for a, b in ((0, 600_001), (600_001, n)):
+                m_exp = oracle.out_count(a, b - a, d)
+                outs = [torch.zeros(2 * m_exp, dtype=torch.float32, device="cuda") for _ in range(2)]
+                pieces = [xx[2 * a:2 * b].clone() for xx in dev_in]
+                assert mc.process_device([p.data_ptr() for p in pieces], [o.data_ptr() for o in outs], b - a) == m_exp
+                for c in range(2):
+                    parts[c].append(outs[c].cpu().numpy())
+            res[chunk] = [np.concatenate(p) for p in parts]
+    for c in range(2):
+        assert np.array_equal(res[fir.MC_NEVER_SPLIT][c], res[fir.MC_CHUNK_UNIT][c]), c
+    l2, mx = oracle.err_metrics(res[fir.MC_CHUNK_UNIT][1], oracle.fir_f64(tp[1], dev_in[1].cpu().numpy(), d))
+    assert l2 <= TOL and mx <= TOL, (l2, mx)
 
 
 @pytest.mark.parametrize("i16,nco", [(False, 0.0), (True, 0.0), (False, -0.21), (True, 0.137)])

@@ -439,3 +439,100 @@ def main_dec2():
 
 if __name__ == "__main__":
     main_dec2()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# odd decimation F = 3 (round 4, fir_odd_kernel): a block is F x 1024 input samples; lane l of row r loads the F consecutive samples
+# x[s0 + F (64 r + l) + p]: F phase streams x_p[m] = x[s0 + F m + p] in the load layout of a 1024-point transform, and
+#     y[F m] = sum_p (g_p * x_p)[m],   g_0[k] = h[F k],  g_p[d] = h[F d - p]  (p >= 1, d >= 1)
+# is evaluated as  Z = sum_p FFT1024(x_p) G_p,  y = IFFT1024(Z).  forward_1024 is the mirror image of inverse_dec4 with the twiddles
+# on the INPUTS of its passes (the kernel applies them in (cos, tan) form, fft16_tw):
+#   A: FFT16 over the rows mu0 (m = 64 mu0 + 4 mu1 + mu2, lane = 4 mu1 + mu2) -> slot k0                         (plain)
+#   Y^-1: element k0 of lane 4 mu1 + mu2 -> lane (k0, mu2) = 16 (k0 // 4) + 4 (k0 % 4) + mu2, slot mu1
+#   B: FFT16 over mu1 -> k1, inputs carry (W256^k0)^mu1;   X^-1: element k1 of lane (g, j = 4 i + mu2) -> lane (g, k1), slot j
+#   C: 4-point DFT over mu2 -> k2', inputs carry (W1024^(k0 + 16 k1))^mu2:  slot 4 i + k2' of lane (g, k1) = X[k0 + 16 k1 + 256 k2']
+def forward_1024(v):
+    lane = np.arange(64)
+    g, m = lane // 16, lane % 16
+    a = np.fft.fft(v, axis=0)
+    y = np.zeros_like(a)
+    for ln in range(64):
+        mu1, mu2 = ln // 4, ln % 4
+        for k0 in range(16):
+            y[mu1, 16 * (k0 // 4) + 4 * (k0 % 4) + mu2] = a[k0, ln]
+    j = lane % 16
+    k0_l = 4 * g + j // 4
+    b = np.fft.fft(y * (W(256, k0_l)[None, :] ** np.arange(16)[:, None]), axis=0)
+    x = np.zeros_like(b)
+    for gg in range(4):
+        x[:, 16 * gg:16 * gg + 16] = b[:, 16 * gg:16 * gg + 16].T
+    z = np.zeros_like(x)
+    for i in range(4):
+        base = W(1024, (4 * g + i) + 16 * m)
+        z[4 * i:4 * i + 4] = np.fft.fft(x[4 * i:4 * i + 4] * base[None, :] ** np.arange(4)[:, None], axis=0)
+    return z
+
+
+def k1024_of(slot, lane):
+    return (4 * (lane // 16) + slot // 4) + 16 * (lane % 16) + 256 * (slot % 4)
+
+
+def odd_phase_taps(h, F, p):
+    """g_p: the polyphase component of h that multiplies the phase stream x_p[m] = x[F m + p] (index = delay in outputs)"""
+    gp = np.zeros(1024, dtype=np.asarray(h).dtype)
+    for k in range(len(h)):
+        if (k + p) % F == 0:
+            gp[(k + p) // F] += h[k]
+    return gp
+
+
+def inverse_1024_from_z(z):
+    """inverse_dec4 without its alias fold: z = slot (4 i + k2', lane (g, k1)) -> y[64 mu0 + lane]"""
+    lane = np.arange(64)
+    g = lane // 16
+    a = np.zeros_like(z)
+    for i in range(4):
+        a[4 * i:4 * i + 4] = np.fft.ifft(z[4 * i:4 * i + 4], axis=0) * 4
+    x = np.zeros_like(a)
+    for gg in range(4):
+        x[:, 16 * gg:16 * gg + 16] = a[:, 16 * gg:16 * gg + 16].T
+    j = lane % 16
+    k0_l, mu2_l = 4 * g + j // 4, j % 4
+    b = np.fft.ifft(x * (np.conj(W(64, mu2_l))[None, :] ** np.arange(16)[:, None]), axis=0) * 16
+    y = np.zeros_like(b)
+    for src in range(64):
+        for mu1 in range(16):
+            y[k0_l[src], 4 * mu1 + mu2_l[src]] = b[mu1, src]
+    c = np.fft.ifft(y * (np.conj(W(1024, lane))[None, :] ** np.arange(16)[:, None]), axis=0) * 16
+    out = np.zeros(1024, dtype=np.complex128)
+    for mu0 in range(16):
+        out[64 * mu0 + lane] = c[mu0]
+    return out / 1024
+
+
+def odd_block(xblk, h, F):
+    """y[F m], m = 0..1023, of one block of F x 1024 samples (valid from m = ceil((T - 1 + F - 1) / F) on)"""
+    lane = np.arange(64)
+    Z = 0
+    for p in range(F):
+        xp = xblk[p::F]
+        Gp = np.fft.fft(odd_phase_taps(h, F, p))
+        reg = np.stack([xp[64 * r + lane] for r in range(16)])
+        Gl = np.stack([Gp[k1024_of(slot, lane)] for slot in range(16)])
+        Z = Z + forward_1024(reg) * Gl
+    return inverse_1024_from_z(Z)
+
+
+def main_odd():
+    rng = np.random.default_rng(6)
+    for F in (3, 5):
+        h = rng.standard_normal(255)
+        xb = rng.standard_normal(F * 1024) + 1j * rng.standard_normal(F * 1024)
+        y = odd_block(xb, h, F)
+        full = np.convolve(xb, h)[:F * 1024][::F]
+        ovl = -(-(255 - 1 + F - 1) // F)
+        print("odd block F = %d: valid-part err %.3g" % (F, np.max(np.abs(y[ovl:] - full[ovl:]))))
+
+
+if __name__ == "__main__":
+    main_odd()
