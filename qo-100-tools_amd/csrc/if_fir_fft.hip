@@ -212,6 +212,33 @@ __device__ __forceinline__ void fft16_tw(cf (&v)[16], const f2v *e)
                       v[q], v[q + 4], v[q + 8], v[q + 12]);
 }
 
+// The same with the table in two pieces (round 4, full-rate pipeline): the first stage's entries at s1[0], s1[S1], s1[2 S1]; the
+// second stage's from the SHARED table T of the triples (b, b^2, b^3 with the third as (c3 / c1, t3)) of b = W4096^m, m = 0..1023:
+// entry (b W16^q)^(j+1) = T_j[m + 256 q] at tq[1024 j + 256 q] (three arrays of 1024 entries; tq = T + tsw(m)).
+template <bool INV, int S1>
+__device__ __forceinline__ void fft16_tw_T(cf (&v)[16], const f2v *s1, const f2v *tq)
+{
+    cf y[4][4];
+    {
+        const cf e1 = s1[0], e2 = s1[S1], e3 = s1[2 * S1];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            bfly4_tw<INV>(v[i], v[i + 4], v[i + 8], v[i + 12], e1, e2, e3, y[0][i], y[1][i], y[2][i], y[3][i]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        bfly4_tw<INV>(y[q][0], y[q][1], y[q][2], y[q][3], tq[256 * q], tq[1024 + 256 * q], tq[2048 + 256 * q], v[q], v[q + 4], v[q + 8],
+                      v[q + 12]);
+}
+// Position of entry m in an array of T: the low five bits are mixed with bits 5..7 so that both users' gathers -- m = lane + 64 rho
+// + 256 q (last inverse pass) and m = 4 (lane / 16) + i + 16 (lane % 16) + 256 q (forward pass 3) -- put the 32 lanes of a half
+// wave on 32 different 8-byte bank slots (checked exhaustively by tests/test_host.py); bits 8, 9 are untouched: + 256 q stays an
+// offset.  Host twin: fft_tsw.
+__host__ __device__ __forceinline__ constexpr unsigned tsw(unsigned m)
+{
+    return (m & ~31u) | ((m ^ (m >> 5)) & 1u) | (((m >> 1) ^ (m >> 6)) & 1u) << 1 | (m & 4u) | (((m >> 3) ^ (m >> 7)) & 1u) << 3 | (m & 16u);
+}
+
 __device__ __forceinline__ void swap32(cf &vdst, cf &src)
 {
     u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(vdst.x), __float_as_uint(src.x), false, false);
@@ -253,6 +280,10 @@ static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 //   LDS_TWD: inverse, last pass    [e*64 + lane]            b = W1024^lane
 //   LDS_TWE: inverse, middle pass  [e*4 + lane%4]           b = W64^(lane%4)
 //   LDS_HP : G'[m0][q] = b^m0 G[m0][q] (the factor pass 3's first stage still owes, merged into the table)
+// Image of the full-rate pipeline (D = 1, the selecting store, their accumulating forms; same size again):
+//   LDS_TW1: [0, 6 KB) forward pass 3, first stage, as above; [8 KB, 32 KB) T: three arrays of 1024 entries (fft16_tw_T, tsw)
+//   LDS_TW2: forward pass 2 as above;  LDS_TWD: inverse pass 2 [e*16 + lane%16], b = W256^(lane%16);  LDS_HP: H / 4096
+constexpr int LDS_TT = LDS_TW1 + 8192;
 // Row loads: the first and last EDGE rows of a block keep the default cache policy, the rows in between are `nt`.  EDGE = the block
 // overlap (the neighbouring block finds the shared rows in L2, round 2).  Round 4 swept larger values (IF_FIR_FFT_EDGE_MIN_FULL /
 // _DEC for the full-rate pipeline / the decimating tails, profiles/r04_edge_rows.txt): 2^28-sample launches lose 2-3 % with more
@@ -312,6 +343,19 @@ __device__ __forceinline__ void exchange1_inv(cf (&r)[64])
             swap32(r[4 * k0 + rho], r[4 * (k0 + 8) + rho]);
 }
 
+// Lanes exchange data through LDS in several places below: one phase of writes, one of reads.  The hardware executes a wave's LDS
+// instructions in order, but for the COMPILER these are plain loads and stores of one thread: where it can prove that a read
+// never overlaps the thread's own writes it may move it across them (round 4: it did, in the odd-decimation kernel's transposition).
+// A compiler-level fence between the phases makes the order independent of what alias analysis can or cannot prove.
+#ifndef IF_FIR_FFT_LDS_FENCE
+#define IF_FIR_FFT_LDS_FENCE 1
+#endif
+#if IF_FIR_FFT_LDS_FENCE
+#define LDS_FENCE() asm volatile("" ::: "memory")
+#else
+#define LDS_FENCE() (void)0
+#endif
+
 // 16x16 transposition inside each 16-lane row: element (i, j) of lane (g, m) -> lane (g, j), slot (i, m)
 __device__ __forceinline__ void exchange2(cf (&r)[64], char *xb, int lane)
 {
@@ -324,11 +368,13 @@ __device__ __forceinline__ void exchange2(cf (&r)[64], char *xb, int lane)
 #pragma unroll
         for (int j = 0; j < 16; j++)
             *reinterpret_cast<f2v *>(wr + j * XROW) = r[phys(i, j)];
+        LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < 16; j++)
         {
             r[phys(i, j)] = *reinterpret_cast<const f2v *>(rd + j * 8);
         }
+        LDS_FENCE();
     }
 }
 
@@ -572,9 +618,11 @@ __device__ __forceinline__ void inverse_tail256(cf (&a)[16], cf (&c)[16], const 
 #pragma unroll
         for (int j = 0; j < 16; j++)
             *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
+        LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < 16; j++)
             a[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+        LDS_FENCE();
     }
     fft16<true>(a); // over k1 -> mu1
 #pragma unroll
@@ -587,9 +635,11 @@ __device__ __forceinline__ void inverse_tail256(cf (&a)[16], cf (&c)[16], const 
 #pragma unroll
         for (int j = 0; j < 16; j++)
             *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
+        LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < 16; j++)
             c[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+        LDS_FENCE();
     }
     fft16<true>(c); // over k0 -> mu0
 }
@@ -627,9 +677,11 @@ __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16],
 #pragma unroll
         for (int j = 0; j < 16; j++)
             *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
+        LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < 16; j++)
             a[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+        LDS_FENCE();
     }
     fft16_tw<true, 4>(a, tb + (lane & 3)); // over k1 -> mu1
     {
@@ -639,9 +691,11 @@ __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16],
 #pragma unroll
         for (int j = 0; j < 16; j++)
             *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
+        LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < 16; j++)
             c[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+        LDS_FENCE();
     }
     fft16_tw<true, 64>(c, tc + lane); // over k0 -> mu0
 }
@@ -656,7 +710,7 @@ __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16],
 // is evaluated as  Z = sum_p FFT1024(x_p) G_p,  y = IFFT1024(Z):  F forward 1024-point transforms (the mirror image of the
 // decimate-by-4 kernel's small inverse, twiddles in (cos, tan) form on the inputs), F x 16 complex MACs per lane and ONE
 // inverse -- 3 x 212 + 96 + 208 = 940 packed instructions per 2688 input samples at F = 3 (tools/fft_model.py odd_block).
-// The first 64 OVLR outputs of a block are dropped (OVLR = 2, 4 or 8 rows: (T - 1 + F - 1) / F <= 64 OVLR).  Decimations F x sub
+// The first 64 OVLR outputs of a block are dropped (OVLR = 2 or 4 rows: (T - 1 + F - 1) / F <= 64 OVLR; <= 383 / 767 taps).  Decimations F x sub
 // (9, 15, 21, ...; 25, 35, 55) keep every sub-th output of this tail (KeepEvery, as behind the even tails).
 // LDS image (fft_build_tables_odd): G_p [(p*16 + slot)*64 + lane] | TB [e*16 + k0] (forward middle pass, b = W256^k0) |
 // TC [(i*3 + e)*64 + lane] (forward last pass, b = W1024^(k0 + 16 k1)) | TWD, TWE (the inverse's tables, as in the decimate-by-4
@@ -686,9 +740,11 @@ __device__ __forceinline__ void forward_1024_tan(cf (&v)[16], cf (&z)[16], const
 #pragma unroll
         for (int j = 0; j < 16; j++)
             *reinterpret_cast<f2v *>(wr + j * 8) = v[j];
+        LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < 16; j++)
             y[j] = *reinterpret_cast<const f2v *>(rd + j * XROW);
+        LDS_FENCE();
         fft16_tw<false, 16>(y, tb + k0); // over mu1 -> k1
     }
     {
@@ -698,9 +754,11 @@ __device__ __forceinline__ void forward_1024_tan(cf (&v)[16], cf (&z)[16], const
 #pragma unroll
         for (int j = 0; j < 16; j++)
             *reinterpret_cast<f2v *>(wr + j * XROW) = y[j];
+        LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < 16; j++)
             y[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
+        LDS_FENCE();
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -720,7 +778,7 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
     using L = OddLds<F>;
     constexpr int ISZ = I16 ? 4 : 8;
     constexpr int LOUT = 1024 - 64 * OVLR, LIN = F * LOUT, OVL = F * 64 * OVLR;
-    constexpr bool LATE_LAST = NCO && SUB && !I16;
+    constexpr bool LATE_LAST = NCO; // (the NCO's lane phasor and row table reads raise the pressure behind the inverse)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const char *in = reinterpret_cast<const char *>(in_);
     const int lane = threadIdx.x & 63;
@@ -780,17 +838,60 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
     const f2v *ncob = reinterpret_cast<const f2v *>(smem + L::NCO);
     (void)ncob;
     char *xb = smem + L::XB + wid * XBUF;
-    cf x[F][16]; // x[p][row]: sample F (64 row + lane) + p of the block (int16 input: the raw pair in .x until it is used)
-    // row loads of one phase: 8 (4) bytes per lane, F x 8 bytes apart -- the F loads of a row cover one contiguous piece
+    // x[p][row]: after the transposition below, sample F (64 row + lane) + p of the block = x_p[64 row + lane].  It is LOADED
+    // coalesced -- piece p of row r = the 64 samples F 64 r + 64 p + lane, 512 contiguous bytes per instruction -- and brought into
+    // the in-lane order through the wave's LDS buffer, four rows at a time (phase_transpose).  The first form of this kernel loaded
+    // the F samples of a lane directly (8 bytes per lane, 24 apart): every instruction then touched all 12 lines of a row, three
+    // times the address work of the texture unit, and the kernel ran 1.16 ms where the selecting store takes 0.76
+    // (profiles/r04_odd_decimation.txt).  int16 input: the raw pair sits in .x until it is used.
+    cf x[F][16];
     auto load_phase = [&](srd_t srd, int p) {
 #pragma unroll
         for (int r = 0; r < 16; r++)
         {
-            const unsigned vo = ((unsigned)lane * F + (unsigned)p) * ISZ, so = (unsigned)(r * 64 * F * ISZ);
+            const unsigned vo = (unsigned)lane * ISZ, so = (unsigned)((r * F + p) * 64 * ISZ);
             if constexpr (I16)
                 x[p][r].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, vo, so, IF_FIR_FFT_LOAD_AUX(0)));
             else
                 x[p][r] = buf_load<IF_FIR_FFT_LOAD_AUX(0)>(srd, vo, so);
+        }
+    };
+    // coalesced pieces -> phase streams, in place: row r's F pieces are written side by side (sample 64 j + lane of the row at
+    // byte (64 j + lane) ISZ) and read back as the lane's own F consecutive samples (F lane + p).  The reads are F ISZ bytes
+    // apart: 6 (3) dwords, conflict-free over 32 lanes.  Four rows per round (4 x 1536 B of the 8.8 KB buffer).
+    auto phase_transpose = [&]() {
+        constexpr int ROWB = 64 * F * ISZ;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4)
+        {
+#pragma unroll
+            for (int r = r0; r < r0 + 4; r++)
+#pragma unroll
+                for (int p = 0; p < F; p++)
+                {
+                    char *wr = xb + (r - r0) * ROWB + (64 * p + lane) * ISZ;
+                    if constexpr (I16)
+                        *reinterpret_cast<float *>(wr) = x[p][r].x;
+                    else
+                        *reinterpret_cast<f2v *>(wr) = x[p][r];
+                }
+            // The lanes exchange data here, and for ONE lane a read at byte F ISZ lane + ISZ p never overlaps one of its own writes
+            // at ISZ lane + 64 ISZ p' (the difference is 8 mod 16): without a fence the compiler is free to move such a read past
+            // the next round's writes -- it did, the first build of this form filtered garbage.  (The hardware executes a wave's
+            // LDS instructions in order; the other exchanges of this file cannot be proven alias-free and keep their order.)
+            asm volatile("" ::: "memory"); // (required here, not IF_FIR_FFT_LDS_FENCE's choice)
+#pragma unroll
+            for (int r = r0; r < r0 + 4; r++)
+#pragma unroll
+                for (int p = 0; p < F; p++)
+                {
+                    const char *rd = xb + (r - r0) * ROWB + (F * lane + p) * ISZ;
+                    if constexpr (I16)
+                        x[p][r].x = *reinterpret_cast<const float *>(rd);
+                    else
+                        x[p][r] = *reinterpret_cast<const f2v *>(rd);
+                }
+            asm volatile("" ::: "memory");
         }
     };
     int64_t blk = queue_take(dq, simd, nblocks, nblocks);
@@ -799,6 +900,7 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
     while (blk < nblocks)
     {
         const int64_t s0 = blk * LIN - OVL + n0;
+        bool inlane = false;
         if (!loaded && !(diag & 1))
         {
             if (s0 >= 0)
@@ -827,8 +929,11 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
                         else
                             x[p][r] = buf_load(srd_in, oi, 0) + buf_load(srd_h, oh, 0);
                     }
+                inlane = true; // (this block was fetched in the lanes' own order: no transposition)
             }
         }
+        if (!inlane)
+            phase_transpose();
         int64_t blk_next = nblocks;
         bool next_fast = false;
         srd_t nsrd = make_srd(in, 0);
@@ -855,15 +960,18 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
                 next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
                 nsrd = make_srd(in + (next_fast ? s0n : 0) * ISZ, next_fast ? (N - s0n) * ISZ : 0);
             }
-            // this phase's 16 registers are dead: refill them with the next block's (the float32 instantiation with NCO and thinning
-            // issues the last phase's loads behind the inverse: its store path's index arithmetic would otherwise spill)
-            if (next_fast && !(LATE_LAST && p == F - 1))
+            // this phase's 16 registers are dead: refill them with the next block's (the instantiations with an NCO issue the last
+            // two phases' loads behind the inverse: their store path would otherwise spill)
+            if (next_fast && !(LATE_LAST && p >= F - 2))
                 load_phase(nsrd, p);
         }
         cf c[16];
         inverse_dec4_tan(zacc, c, twe, twd, xb, lane);
         if (LATE_LAST && next_fast)
+        {
+            load_phase(nsrd, F - 2);
             load_phase(nsrd, F - 1);
+        }
         const int64_t obase = blk * LOUT;
         // SPEC 3.2: output m = obase + 64 (mu0 - OVLR) + lane of the fs/F-rate tail is rotated by phasor(phi0 + delta m) = A(lane) B(row)
         cf a_lane = {1.0f, 0.0f};
@@ -982,7 +1090,6 @@ hipError_t launch_fft_odd(const LaunchArgs &a)
     }
     IF_FIR_ODD_SWITCH(3, 2)
     IF_FIR_ODD_SWITCH(3, 4)
-    IF_FIR_ODD_SWITCH(3, 8)
 #undef IF_FIR_ODD_SWITCH
     return hipErrorInvalidConfiguration;
 }
@@ -1018,6 +1125,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // decimate-by-4 kernels (single channel incl. the multiples of 4, and the bank at decimation 4): twiddles in (cos, tan) form
     // on the inputs of passes 2 and 3 and of the small inverse (round 4); every other tail keeps round 3's form and tables
     constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4);
+    // the full-rate pipeline the same way, forward and inverse (the inverse's twiddles already sat on the inputs of its passes)
+    constexpr bool TANF = IF_FIR_FFT_TAN && !DEC4;
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
     const char *in = reinterpret_cast<const char *>(in_);
@@ -1153,6 +1262,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     char *xb = smem + LDS_XB + wid * XBUF;
     (void)twd;
     (void)twe;
+    // full-rate pipeline: the shared table T and this lane's three positions in it (tsw)
+    const f2v *tt = reinterpret_cast<const f2v *>(smem + LDS_TT);
+    const unsigned t_fwd3 = tsw(4u * ((unsigned)lane >> 4) + 16u * ((unsigned)lane & 15u)); // + i: xor (bits 0, 1 of the position)
+    const unsigned t_inv1 = tsw((unsigned)lane), t_inv1s = tsw(4u * (unsigned)lane);
+    (void)tt; (void)t_fwd3; (void)t_inv1; (void)t_inv1s;
 
     // diagnostics (only with a debug buffer): phase stamps of the first 32 iterations of a few waves
     int dbg_it = 0;
@@ -1194,6 +1308,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         blk = (wid < act_waves) ? (int64_t)blockIdx.x * act_waves + wid : nblocks;
     }
     const unsigned voff = (unsigned)lane * 8u;
+    // (end game: from this global group on; groups are handed out in global order, so a workgroup whose current group has come
+    // this far is in the launch's last round or two)
+    const int64_t endgame_from = (nblocks_main + FFT_WAVES - 1) / FFT_WAVES - (int64_t)gridDim.x * ((diag & 8192) ? 2 : 1);
     while (blk < nblocks)
     {
         FFT_STAMP(0);
@@ -1246,7 +1363,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
             for (int j = 0; j < 16; j++)
             {
-                if (j == 0 || TAN) // (TAN: the twiddle W4096^((lane + 64 rho) k0) is applied on the inputs of passes 2 and 3)
+                if (j == 0 || TAN || TANF) // (the twiddle W4096^((lane + 64 rho) k0) is applied on the inputs of passes 2 and 3)
                     r[4 * j + rho] = t[j];
                 else
                 {
@@ -1270,7 +1387,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
             for (int j = 0; j < 16; j++)
                 t[j] = r[phys(i, j)];
-            if constexpr (TAN)
+            if constexpr (TAN || TANF)
             {
                 // inputs carry W256^(n1 k0), k0 = 4 (lane / 16) + i: the part of pass 1's twiddle that depends on n1; the rest,
                 // W4096^(n2 k0), joins this pass's own W256^(n2 k1) on the inputs of pass 3
@@ -1303,6 +1420,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         exchange2(r, xb, lane);
         FFT_STAMP(4);
         int64_t blk_next = blk + 1;
+        bool endgame = false;
         if (static_map)
         {
             blk_next = blk + static_stride;
@@ -1311,7 +1429,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         {
             // taken here: the block's own rows have all landed and the next block's are not issued yet, so the wait
             // behind the (rare) global atomic inside drains nothing
-            blk_next = queue_take(dq, simd, nblocks_main, nblocks);
+            // End game (round 4, development bits 4096 / 8192 = the last 1 / 2 groups per workgroup): a wave that takes its next
+            // block HERE, in the middle of the current one, can end up holding one and a half blocks while a wave that asks a
+            // moment later gets nothing and leaves -- the waves of a launch end over a spread of two block times.  In the end
+            // game the take is deferred until the current block is stored (no prefetch for that block, but whoever is free takes it).
+            endgame = (diag & (4096 | 8192)) && (int64_t)(unsigned)(dq.cur_load() >> 32) >= endgame_from;
+            blk_next = endgame ? nblocks : queue_take(dq, simd, nblocks_main, nblocks);
         }
         const int64_t s0n = blk_next * L - OVL + n0 - in_shift;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
@@ -1966,7 +2089,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     t[j] = r[phys(i, j)];
-                fft16<false>(t);
+                if constexpr (TANF) // inputs carry b^n2, b = W4096^(k0 + 16 k1): second-stage entries at T[k0 + 16 k1 + 256 q]
+                    fft16_tw_T<false, 64>(t, tw1 + i * 3 * 64 + lane, tt + (t_fwd3 ^ (unsigned)i));
+                else
+                    fft16<false>(t);
                 // ---- pointwise multiply by H/4096 and start the inverse (pass 3^-1) in the same registers -------
 #pragma unroll
                 for (int j = 0; j < 16; j++)
@@ -1981,6 +2107,15 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             for (int i = 0; i < 4; i++)
             {
                 cf t[16];
+                if constexpr (TANF)
+                {
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        t[j] = r[phys(i, j)];
+                    fft16_tw<true, 16>(t, twd + (lane & 15)); // inputs carry conj(W256^n2)^k1, n2 = lane % 16
+                }
+                else
+                {
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                 {
@@ -1990,6 +2125,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         t[j] = cmul_v<true>(r[phys(i, j)], tw2[j * 16 + (lane & 15)]);
                 }
                 fft16<true>(t);
+                }
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     r[phys(i, j)] = t[j];
@@ -2029,6 +2165,17 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             for (int rho = 0; rho < 4; rho++)
             {
                 cf t[16];
+                if constexpr (TANF)
+                {
+                    // inputs carry conj(b)^k0, b = W4096^(lane + 64 rho): first-stage entries (b^4, b^8, b^12) at T[4 lane + 256 rho],
+                    // second-stage entries at T[lane + 64 rho + 256 q]
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        t[j] = r[4 * j + rho];
+                    fft16_tw_T<true, 1024>(t, tt + t_inv1s + 256 * rho, tt + ((t_inv1 ^ (unsigned)(((rho & 1) << 1) | ((rho >> 1) << 3))) + 64 * rho));
+                }
+                else
+                {
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                 {
@@ -2038,6 +2185,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         t[j] = cmul_v<true>(r[4 * j + rho], tw1[(rho * 16 + j) * 64 + lane]);
                 }
                 fft16<true>(t);
+                }
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                 {
@@ -2076,7 +2224,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         FFT_STAMP(7);
         dbg_it++;
         loaded = next_fast;
-        blk = blk_next;
+        blk = endgame ? queue_take(dq, simd, nblocks_main, nblocks) : blk_next;
     }
 #ifndef IF_FIR_FFT_STAMPS
     if (dbg && lane == 0)
@@ -2222,7 +2370,9 @@ bool fft_odd_tail(int T, int D, int *pF, int *pSub, int *pOvlr)
         if (F > 1)
         {
             const int need = (T - 1 + F - 1 + F - 1) / F; // outputs of a block that see samples ahead of it
-            ovlr = need <= 128 ? 2 : need <= 256 ? 4 : need <= 512 ? 8 : 0;
+            // (8 dropped rows -- up to 1535 taps -- were built and measured 18 % slower than the selecting store: half of every
+            // block is overlap, profiles/r04_odd_decimation.txt)
+            ovlr = need <= 128 ? 2 : need <= 256 ? 4 : 0;
             if (!ovlr)
                 F = 1;
         }
@@ -2470,7 +2620,7 @@ static void tan_fft16_entries(double th, float *out, int stride)
 //   [64 KB, 66 KB)  tw2[k1*16 + n2]            = W256^(n2*k1)
 //   [66 KB, 82 KB)  twd, twe: twiddles of the decimate-by-4 1024-point inverse
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale,
-                      float *tables /* FFT_TABLE_FLOATS floats */, int bank)
+                      float *tables /* FFT_TABLE_FLOATS floats */, int bank, int full_rate)
 {
     const double PI2 = 6.283185307179586476925286766559;
     float *tw1 = tables, *hp = tables + 2 * 4096, *tw2 = tables + 4 * 4096;
@@ -2603,6 +2753,47 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
     {
         for (int e = 0; e < 2 * 4096; e++)
             hp[e] = (float)hd[e];
+#if IF_FIR_FFT_TAN
+        if (full_rate)
+        {
+            // the full-rate pipeline's twiddles in (cos, tan) form (LDS map at the top of the file): forward pass 2 and the first
+            // stage of forward pass 3 as in the decimate-by-4 image; the shared table T; inverse pass 2
+            for (int e = 0; e < 2 * 4096; e++)
+                tw1[e] = 0.0f;
+            for (int e = 0; e < 2 * 256; e++)
+                tw2[e] = 0.0f;
+            for (int e = 0; e < 2 * 1024; e++)
+                twd[e] = 0.0f;
+            for (int i = 0; i < 4; i++)
+            {
+                for (int lane = 0; lane < 64; lane++)
+                {
+                    float all[30];
+                    tan_fft16_entries(-PI2 * (double)((4 * (lane / 16) + i) + 16 * (lane % 16)) / 4096.0, all, 1);
+                    for (int e = 0; e < 3; e++)
+                    {
+                        tw1[2 * ((i * 3 + e) * 64 + lane) + 0] = all[2 * e];
+                        tw1[2 * ((i * 3 + e) * 64 + lane) + 1] = all[2 * e + 1];
+                    }
+                }
+                for (int g = 0; g < 4; g++)
+                    tan_fft16_entries(-PI2 * (double)(4 * g + i) / 256.0, tw2 + 2 * (i * 60 + g), 4);
+            }
+            float *tt = tw1 + 2 * 1024; // (LDS_TT)
+            for (int m = 0; m < 1024; m++)
+            {
+                const double th = -PI2 * (double)m / 4096.0;
+                const unsigned pos = tsw((unsigned)m);
+                tan_entry(th, 0.0, tt + 2 * pos);
+                tan_entry(2.0 * th, 0.0, tt + 2 * (1024 + pos));
+                tan_entry(3.0 * th, tan_cos(th), tt + 2 * (2048 + pos));
+            }
+            for (int n2 = 0; n2 < 16; n2++)
+                tan_fft16_entries(-PI2 * (double)n2 / 256.0, twd + 2 * n2, 16);
+        }
+#else
+        (void)full_rate;
+#endif
         return;
     }
     // decimate-by-4 kernels: the table holds G[m0][q] = W16^(m0 q) * sum_p H(q + 4p) W4^(m0 p) at ((i*16 + 4*m0 + q)*64 + lane)

@@ -179,6 +179,9 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
     // NCO row steps of decimation 4; decimation 2 (and 6, 10, ...) and the selecting-store route the plain one
     const int F = tail_factor(ctx);
     const int tabD = F == 4 ? 4 : 1;
+    // D = 1 and the selecting store (odd decimations; development variant 3000: decimation 2, 6, 10, ... on it as well): the
+    // full-rate pipeline's image
+    const int full = (F == 1 || (F == 2 && ctx->variant == 3000)) ? 1 : 0;
     const uint32_t tab_nco = 0u - ctx->nco_word * (F == 4 ? 4u : 1u);
     if (odd)
         if_fir::fft_build_tables_odd(eff_taps(ctx), ctx->T, eff_ctaps(ctx), oddF, 0u - ctx->nco_word * (uint32_t)oddF,
@@ -187,12 +190,12 @@ static uint8_t ensure_fft_tables(if_fir_ctx *ctx)
     {
         // two partitions: each a filter of <= 2048 taps with its own table image
         const int step = eff_ctaps(ctx) ? 2 : 1, part = 2048;
-        if_fir::fft_build_tables(eff_taps(ctx), part, eff_ctaps(ctx), tabD, tab_nco, ctx->in_i16 ? 0x1p-15 : 1.0, tab);
+        if_fir::fft_build_tables(eff_taps(ctx), part, eff_ctaps(ctx), tabD, tab_nco, ctx->in_i16 ? 0x1p-15 : 1.0, tab, 0, full);
         if_fir::fft_build_tables(eff_taps(ctx) + (size_t)step * part, ctx->T - part, eff_ctaps(ctx), tabD, tab_nco,
-                                 ctx->in_i16 ? 0x1p-15 : 1.0, tab + if_fir::FFT_TABLE_FLOATS);
+                                 ctx->in_i16 ? 0x1p-15 : 1.0, tab + if_fir::FFT_TABLE_FLOATS, 0, full);
     }
     else
-        if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), tabD, tab_nco, ctx->in_i16 ? 0x1p-15 : 1.0, tab);
+        if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), tabD, tab_nco, ctx->in_i16 ? 0x1p-15 : 1.0, tab, 0, full);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables, sizeof(float) * tab_floats);
@@ -482,8 +485,10 @@ IF_FIR_API uint8_t if_fir_set_tuning(if_fir_ctx_t *pCtx, uint32_t ulVariant)
         return 0;
     }
 #endif
+    int tailF = 1;
+    (void)if_fir::fft_tail(pCtx->T, pCtx->D, &tailF, nullptr);
     if (((int)ulVariant == 3000) != (pCtx->variant == 3000) && pCtx->d_fft_tables &&
-        if_fir::fft_odd_tail(pCtx->T, pCtx->D, nullptr, nullptr, nullptr))
+        (if_fir::fft_odd_tail(pCtx->T, pCtx->D, nullptr, nullptr, nullptr) || tailF == 2))
     {
         // the selecting-store route and the odd-decimation kernel take different table images: rebuilt on the next call
         HIP_TRY(pCtx, hipSetDevice(pCtx->device));
@@ -962,7 +967,11 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps
     if (!pfTaps || !pfOut || ulOutFloats < (uint32_t)if_fir::FFT_TABLE_FLOATS ||
         !if_fir::fft_supported((int)ulTaps, (int)ulDecimation) || if_fir::fft_two_partitions((int)ulTaps))
         return 0; // (a two-partition filter is two such images, one per partition of <= 2048 taps)
-    if_fir::fft_build_tables(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, (int)ulDecimation, ulNcoDelta, 1.0, pfOut);
+    // (the image the library would upload for this pair: decimation 4 and its multiples take the merged table, D = 1 and the
+    // selecting store the full-rate pipeline's, decimation 2, 6, 10, ... the plain one)
+    int F = 1;
+    if_fir::fft_tail((int)ulTaps, (int)ulDecimation, &F, nullptr);
+    if_fir::fft_build_tables(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, F == 4 ? 4 : 1, ulNcoDelta, 1.0, pfOut, 0, F == 1 ? 1 : 0);
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
 }
 

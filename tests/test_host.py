@@ -116,6 +116,27 @@ def test_mc_owner_matches_channel_map_and_init_argument_errors(fir):
         fir.IfFirMc(taps, 1, 1000, rank=0, world=2)               # two ranks without the bootstrap id
 
 
+def _tsw(m):
+    """position of entry m in an array of the full-rate pipeline's shared twiddle table (tsw in csrc/if_fir_fft.hip)"""
+    return ((m & ~31) | ((m ^ (m >> 5)) & 1) | ((((m >> 1) ^ (m >> 6)) & 1) << 1) | (m & 4) | ((((m >> 3) ^ (m >> 7)) & 1) << 3) | (m & 16))
+
+
+def test_shared_twiddle_table_gathers_are_conflict_free():
+    """Round 4: the full-rate pipeline's last inverse pass reads the shared table at m = lane + 64 rho + 256 q (second stage) and
+    m = 4 lane + 256 rho (first stage), its forward pass 3 at m = 4 (lane / 16) + i + 16 (lane % 16) + 256 q.  With the position
+    function tsw the 32 lanes of either half of a wave always land on 32 different 8-byte bank slots, and + 256 q stays a plain offset."""
+    lane = np.arange(64)
+    pats = [lane + 64 * rho + 256 * q for rho in range(4) for q in range(4)]
+    pats += [4 * lane + 256 * rho for rho in range(4)]
+    pats += [4 * (lane // 16) + i + 16 * (lane % 16) + 256 * q for i in range(4) for q in range(4)]
+    for ms in pats:
+        for half in (0, 1):
+            slots = {_tsw(int(v)) % 32 for v in ms[32 * half:32 * half + 32]}
+            assert len(slots) == 32, ms
+    assert all(_tsw(m + 256) == _tsw(m) + 256 for m in range(768))
+    assert all(_tsw(4 * (g + 4 * k1) + i) == _tsw(4 * (g + 4 * k1)) ^ i for g in range(4) for k1 in range(16) for i in range(4))
+
+
 def _bin_of(i, k2, lane):
     """frequency bin held by table entry (i, k2, lane) of the overlap-save kernel (csrc/if_fir_fft.hip, fft_build_tables)"""
     return (4 * (lane // 16) + i) + 16 * (lane % 16) + 256 * k2
@@ -140,33 +161,53 @@ def test_overlap_save_tables_against_numpy(fir, t, d, ctaps):
     lane = np.arange(64)
     W = lambda n, e: np.exp(-2j * np.pi * (np.asarray(e) % n) / n)   # noqa: E731
     # twiddles
-    if d != 4:
+    merged = d % 4 == 0          # decimation 4 and its multiples: the decimate-by-4 image (merged table G')
+    full_rate = d % 2 == 1       # D = 1 and the selecting store: the full-rate pipeline's image (round 4)
+
+    def triple(e1, e2, e3):      # (c, t) entries of one butterfly -> its three twiddles; the third entry holds (c3 / c1, t3)
+        c1, t1 = e1.real.astype(np.float64), e1.imag.astype(np.float64)
+        c2, t2 = e2.real.astype(np.float64), e2.imag.astype(np.float64)
+        r3, t3 = e3.real.astype(np.float64), e3.imag.astype(np.float64)
+        return c1 * (1 + 1j * t1), c2 * (1 + 1j * t2), r3 * c1 * (1 + 1j * t3)
+
+    def check_entries(entries, base):           # entries: (15, n) complex64 = (c, t) pairs; base: (n,) complex
+        w = triple(entries[0], entries[1], entries[2])
+        for k, got in zip((4, 8, 12), w):
+            assert np.allclose(got, base ** k, atol=3e-7), k
+        for q in range(4):
+            b = base * W(16, q)
+            w = triple(entries[3 + 3 * q], entries[4 + 3 * q], entries[5 + 3 * q])
+            for k, got in zip((1, 2, 3), w):
+                assert np.allclose(got, b ** k, atol=3e-7), (q, k)
+        assert np.all(np.isfinite(entries.view(np.float32)))
+
+    if not merged and not full_rate:
         for rho in range(4):
             for k0 in range(16):
                 assert np.allclose(tab["tw1"][(rho * 16 + k0) * 64:(rho * 16 + k0) * 64 + 64], W(4096, (lane + 64 * rho) * k0), atol=1e-7)
         for k1 in range(16):
             assert np.allclose(tab["tw2"][k1 * 16:k1 * 16 + 16], W(256, np.arange(16) * k1), atol=1e-7)
+    elif full_rate:
+        # forward pass 2 and the first stage of forward pass 3 as in the decimate-by-4 image; the shared table T of the triples
+        # (b, b^2, b^3), b = W4096^m, at position tsw(m) of three arrays of 1024 entries; inverse pass 2: b = W256^(lane % 16)
+        g, m = lane // 16, lane % 16
+        for i in range(4):
+            base3 = W(4096, (4 * g + i) + 16 * m)
+            e = tab["tw1"][i * 3 * 64:(i * 3 + 3) * 64].reshape(3, 64)
+            for k, got in zip((4, 8, 12), triple(e[0], e[1], e[2])):
+                assert np.allclose(got, base3 ** k, atol=3e-7), (i, k)
+            check_entries(tab["tw2"][i * 60:(i + 1) * 60].reshape(15, 4), W(256, 4 * np.arange(4) + i))
+        tt = tab["tw1"][1024:4096].reshape(3, 1024)
+        mm = np.arange(1024)
+        pos = np.array([_tsw(int(v)) for v in mm])
+        assert sorted(pos) == list(range(1024))
+        for k, got in zip((1, 2, 3), triple(tt[0][pos], tt[1][pos], tt[2][pos])):
+            assert np.allclose(got, W(4096, mm) ** k, atol=3e-7), k
+        check_entries(tab["twd"][:15 * 16].reshape(15, 16), W(256, np.arange(16)))
     else:
         # round 4: the decimate-by-4 kernels take their twiddles in (cos, tan) form, w = c (1 + j t) stored as (c, t), on the
         # INPUTS of the 16-point transforms: 15 entries per base twiddle b -- b^4, b^8, b^12 (the third as (c3 / c1, t3)), then for
         # q = 0..3 the three twiddles (b W16^q)^1..3 (fft16_tw in csrc/if_fir_fft.hip)
-        def triple(e1, e2, e3):
-            c1, t1 = e1.real.astype(np.float64), e1.imag.astype(np.float64)
-            c2, t2 = e2.real.astype(np.float64), e2.imag.astype(np.float64)
-            r3, t3 = e3.real.astype(np.float64), e3.imag.astype(np.float64)
-            return c1 * (1 + 1j * t1), c2 * (1 + 1j * t2), r3 * c1 * (1 + 1j * t3)
-
-        def check_entries(entries, base):           # entries: (15, n) complex64 = (c, t) pairs; base: (n,) complex
-            w = triple(entries[0], entries[1], entries[2])
-            for k, got in zip((4, 8, 12), w):
-                assert np.allclose(got, base ** k, atol=3e-7), k
-            for q in range(4):
-                b = base * W(16, q)
-                w = triple(entries[3 + 3 * q], entries[4 + 3 * q], entries[5 + 3 * q])
-                for k, got in zip((1, 2, 3), w):
-                    assert np.allclose(got, b ** k, atol=3e-7), (q, k)
-            assert np.all(np.isfinite(entries.view(np.float32)))
-
         g, m = lane // 16, lane % 16
         for i in range(4):
             base3 = W(4096, (4 * g + i) + 16 * m)       # pass 3: only the first-stage entries are kept
@@ -190,7 +231,7 @@ def test_overlap_save_tables_against_numpy(fir, t, d, ctaps):
             Hp[i, k2] = H[_bin_of(i, k2, lane)]
     hp = tab["hp"].astype(np.complex128).reshape(4, 16, 64)
     scale = np.max(np.abs(H))
-    if d != 4:
+    if not merged:
         assert np.max(np.abs(hp - Hp)) <= 2e-7 * scale
         return
     # merged table: for random pass-2 outputs t[m] (m = time digit of the last 16-point transform),
@@ -222,7 +263,7 @@ def test_overlap_save_tables_against_numpy(fir, t, d, ctaps):
                     assert np.max(np.abs(direct - via)) <= 3e-7 * scale, (s, i, m0, q)
 
 
-@pytest.mark.parametrize("t,d,ctaps", [(255, 3, False), (383, 9, False), (767, 3, True), (1535, 15, False), (3, 3, False)])
+@pytest.mark.parametrize("t,d,ctaps", [(255, 3, False), (383, 9, False), (767, 3, True), (511, 15, False), (3, 3, False)])
 def test_odd_decimation_tables_against_numpy(fir, t, d, ctaps):
     """Round 4: the table image of the odd-decimation kernel (blocks of 3 x 1024 samples: three forward 1024-point transforms of
     the phase streams x_p[m] = x[3 m + p], Z = sum_p F_p G_p, one inverse; tools/fft_model.py odd_block).  G_p against numpy's FFT
@@ -279,13 +320,13 @@ def test_odd_decimation_tables_against_numpy(fir, t, d, ctaps):
     y = fm.inverse_1024_from_z(Z)
     full = np.convolve(xb, h)[:3 * 1024][::3]
     ovl = -(-(t - 1 + 2) // 3)
-    assert ovl <= 512 and np.max(np.abs(y[ovl:] - full[ovl:])) <= 2e-6 * max(np.max(np.abs(full)), 1e-30)
+    assert ovl <= 256 and np.max(np.abs(y[ovl:] - full[ovl:])) <= 2e-6 * max(np.max(np.abs(full)), 1e-30)
 
 
 def test_odd_decimation_routing(fir):
     """Which (taps, decimation) pairs the odd-decimation kernel serves: decimation 3, 9, 15, ..., 63 (a multiple of 3) with at
-    most 3 x 512 - 1 = 1535 taps; everything else keeps its route (the host-only table hook refuses them)."""
-    for t, d, ok in ((255, 3, True), (1535, 3, True), (1536, 3, False), (255, 9, True), (255, 63, True), (255, 5, False),
+    most 3 x 256 - 1 = 767 taps; everything else keeps its route (the host-only table hook refuses them)."""
+    for t, d, ok in ((255, 3, True), (767, 3, True), (768, 3, False), (1535, 3, False), (255, 9, True), (255, 63, True), (255, 5, False),
                      (255, 7, False), (255, 6, False), (255, 1, False), (4095, 3, False), (1, 3, True)):
         try:
             fir.debug_fft_tables_odd(np.ones(t, np.float32), d)
@@ -386,9 +427,9 @@ def test_no_overlap_save_instantiation_spills():
     assert len(fft) == 194, len(fft)
     for name, res in fft.items():
         assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
-    # round 4: the odd-decimation kernel (blocks of 3 x 1024 samples): 3 overlap lengths x float32 / int16 x NCO x thinning
+    # round 4: the odd-decimation kernel (blocks of 3 x 1024 samples): 2 overlap lengths x float32 / int16 x NCO x thinning
     odd = {k: v for k, v in kernels.items() if "fir_odd_kernel" in k}
-    assert len(odd) == 24, len(odd)
+    assert len(odd) == 16, len(odd)
     for name, res in odd.items():
         assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
 

@@ -130,18 +130,18 @@ def test_stand_in_transport_builds():
 
 def has_decimating_tail(taps, decim):
     """if_fir::fft_tail: every even decimation (the decimate-by-4 / -by-2 tail keeping every sub-th output), any tap count;
-    round 4: and the odd-decimation kernel (decimation 3, 9, 15, ... with at most 1535 taps) -- block grids anchored at the call's
+    round 4: and the odd-decimation kernel (decimation 3, 9, 15, ... with at most 767 taps) -- block grids anchored at the call's
     first output"""
-    return taps <= 4096 and (decim % 2 == 0 or (decim % 3 == 0 and taps <= 1535))
+    return taps <= 4096 and (decim % 2 == 0 or (decim % 3 == 0 and taps <= 767))
 
 
 def block_advance(taps, decim):
     """if_fir::fft_block_advance: new input samples per block of the overlap-save kernel for this filter"""
     if taps > 3073:
         return 2048                                   # two partitions, each on the 32-row kernel
-    if decim % 2 == 1 and decim % 3 == 0 and (taps - 1 + 2 + 2) // 3 <= 512:
+    if decim % 2 == 1 and decim % 3 == 0 and (taps - 1 + 2 + 2) // 3 <= 256:
         need = (taps - 1 + 2 + 2) // 3                # round 4: the odd-decimation kernel, blocks of 3 x 1024 samples
-        return 3 * (1024 - 64 * (2 if need <= 128 else 4 if need <= 256 else 8))
+        return 3 * (1024 - 64 * (2 if need <= 128 else 4))
     rows = 4 if taps - 1 <= 256 else 8 if taps - 1 <= 512 else 16 if taps - 1 <= 1024 else 32 if taps - 1 <= 2048 else 48
     return 4096 - 64 * rows
 

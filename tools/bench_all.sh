@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 O=gpurun_out/$1
 mkdir -p $O
-for w in fir255_dec4_2p28 fir127_2p26 fir255_2p28 fir1023_2p28 fir255_dec4_i16_2p28 fir255_dec4_nco_2p28 fir1023_dec8_2p28 fir255_dec2_2p28 fir2047_dec8_2p26; do
+for w in fir255_dec4_2p28 fir127_2p26 fir255_2p28 fir1023_2p28 fir255_dec4_i16_2p28 fir255_dec4_nco_2p28 fir1023_dec8_2p28 fir255_dec2_2p28 fir2047_dec8_2p26 fir255_dec3_2p28 fir255_dec9_2p28 fir511_dec3_2p28; do
   python3 bench.py --workload $w --no-cpu-baseline --no-extra-configs --steps 50 --warmup 10 > $O/bench_$w.json 2> $O/bench_$w.err
   python3 - "$O/bench_$w.json" <<'PY'
 import json, sys

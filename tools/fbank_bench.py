@@ -2,8 +2,9 @@
 """fbank_bench.py — uniform filter bank (if_fir_channelizer_process_device) against the same channels
 computed one at a time (if_fir_set_nco contexts): time per pass over a 2^log2n-sample wideband stream, whole-output
 comparison of every channel, one JSON line.
-usage: python tools/fbank_bench.py [channels=8] [log2n=28] [taps=255] [decimation=4]   (decimation 4: 4x oversampled fs/16
-channels; 16: the channel rate, all 16 slots from one forward transform, round 3)"""
+usage: python tools/fbank_bench.py [channels=8] [log2n=28] [taps=255] [decimation=4] [freq]   (decimation 4: 4x oversampled fs/16
+channels; 16: the channel rate, all 16 slots from one forward transform, round 3; "freq" (decimation 8, round 4): the channels sit
+at arbitrary centres on the fs/4096 grid -- if_fir_channelizer_process_device_freq -- instead of on slots)"""
 import json
 import os
 import sys
@@ -20,11 +21,19 @@ def main():
     log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 28
     taps_n = int(sys.argv[3]) if len(sys.argv) > 3 else 255
     dec = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+    freq = len(sys.argv) > 5 and sys.argv[5] == "freq"
     n = 1 << log2n
     fir = g.load_pkg().if_fir
     torch.cuda.set_device(0)
     taps = fir.bpf_design(taps_n, 0.0, 0.03 if dec == 4 else 0.02)
     slots = [(2 * c + 1) % 16 for c in range(nch)] if nch <= 8 else list(range(nch))
+    # arbitrary centres: near the slots, 37 + 11 c bins of fs/4096 off them
+    centres = [(((256 * s + 37 + 11 * c) + 2048) % 4096 - 2048) / 4096.0 for c, s in enumerate(slots)]
+
+    def bank(f, ptrs):
+        if freq:
+            return f.channelizer_process_device_freq(centres, x.data_ptr(), ptrs, n)
+        return f.channelizer_process_device(slots, x.data_ptr(), ptrs, n)
     x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
     with fir.IfFir(taps, dec, 0, dev=True) as f:
         m = f.out_count(n)
@@ -36,18 +45,18 @@ def main():
         f.set_stream(stream.cuda_stream)
         ptrs = [o.data_ptr() for o in outs]
         for _ in range(5):
-            f.channelizer_process_device(slots, x.data_ptr(), ptrs, n)
+            bank(f, ptrs)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         steps = 20
         e0.record(stream)
         for _ in range(steps):
-            f.channelizer_process_device(slots, x.data_ptr(), ptrs, n)
+            bank(f, ptrs)
         e1.record(stream)
         torch.cuda.synchronize()
         ms_bank = e0.elapsed_time(e1) / steps
         # the same stream position for the check: one more pass from a reset context
         f.reset()
-        f.channelizer_process_device(slots, x.data_ptr(), ptrs, n)
+        bank(f, ptrs)
         f.synchronize()
     # one channel at a time (what the filter bank replaces)
     ref = torch.empty(2 * m, dtype=torch.float32, device="cuda")
@@ -55,7 +64,7 @@ def main():
     ms_single = 0.0
     for c, s in enumerate(slots):
         with fir.IfFir(taps, dec, 0, dev=True) as f1:
-            f1.set_nco(s / 16.0 if s <= 8 else s / 16.0 - 1.0)   # slots above 8 are negative frequencies
+            f1.set_nco(centres[c] if freq else (s / 16.0 if s <= 8 else s / 16.0 - 1.0))   # slots above 8 are negative frequencies
             f1.set_stream(stream.cuda_stream)
             f1.process_device(x.data_ptr(), ref.data_ptr(), n)
             f1.synchronize()
@@ -71,7 +80,9 @@ def main():
             ms_single += e0.elapsed_time(e1) / 10
     bytes_alg = (8.0 + nch * 8.0 / dec) * n   # one read of the wideband stream + every channel's output
     print(json.dumps({
-        "workload": "uniform filter bank: %d channels x (%d-tap prototype, decimate-by-%d) from one 2^%d-sample stream" % (nch, taps_n, dec, log2n),
+        "workload": "%s: %d channels x (%d-tap prototype, decimate-by-%d) from one 2^%d-sample stream" %
+                    ("filter bank, channels at arbitrary centres (fs/4096 grid)" if freq else "uniform filter bank", nch, taps_n, dec, log2n),
+        "centres": centres if freq else None,
         "bytes_per_input_sample": 8.0 + nch * 8.0 / dec,
         "slots": slots, "filter_bank_ms": round(ms_bank, 4), "one_channel_at_a_time_ms": round(ms_single, 4),
         "speedup": round(ms_single / ms_bank, 2),

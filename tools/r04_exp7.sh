@@ -12,3 +12,7 @@ for w in fir255_dec3_2p28 fir255_dec9_2p28 fir1023_dec3_2p28; do
   timeout -k 10 300 python3 tools/ab_inproc.py $w --variants 0 3000 --rounds 8 --reps 30 2>&1 | grep -v amdgpu.ids | tee -a $O/ab_odd.txt
 done
 for spec in "8 28 255 8" "16 28 255 8"; do timeout -k 10 200 python3 tools/fbank_bench.py $spec 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-700 | tee -a $O/fbank.txt; done
+A=qo-100-tools_amd
+for w in fir127_2p26 fir255_2p28 fir1023_2p28 fir255_dec4_2p28; do
+  timeout -k 10 300 python3 tools/ab_inproc.py $w --libs $A/libif_fir_ab_notan.so $A/libif_fir_dev.so --rounds 8 --reps 30 2>&1 | grep -v amdgpu.ids | tee -a $O/ab_tan_full_rate.txt
+done
