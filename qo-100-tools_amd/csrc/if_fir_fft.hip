@@ -345,10 +345,14 @@ __device__ __forceinline__ void exchange1_inv(cf (&r)[64])
 
 // Lanes exchange data through LDS in several places below: one phase of writes, one of reads.  The hardware executes a wave's LDS
 // instructions in order, but for the COMPILER these are plain loads and stores of one thread: where it can prove that a read
-// never overlaps the thread's own writes it may move it across them (round 4: it did, in the odd-decimation kernel's transposition).
-// A compiler-level fence between the phases makes the order independent of what alias analysis can or cannot prove.
+// never overlaps the thread's own writes it may move it across them (round 4: it did, in the odd-decimation kernel's
+// transposition, which therefore carries a compiler fence).  In the exchanges below that proof is impossible because it would be
+// false: a lane really reads back addresses it has written (exchange2: element j of lane (g, m) goes to g XREG + j XROW + 8 m and
+// the lane reads g XREG + m XROW + 8 j' -- the same address for j = j' = m; the small transposes likewise), so the single-thread
+// order of the language already pins every read behind the writes.  IF_FIR_FFT_LDS_FENCE=1 adds a fence all the same; it costs
+// 0.65 % on the headline (profiles/r04_lds_fence_ab.txt) and is off.
 #ifndef IF_FIR_FFT_LDS_FENCE
-#define IF_FIR_FFT_LDS_FENCE 1
+#define IF_FIR_FFT_LDS_FENCE 0
 #endif
 #if IF_FIR_FFT_LDS_FENCE
 #define LDS_FENCE() asm volatile("" ::: "memory")
@@ -718,8 +722,11 @@ __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16],
 constexpr int ODD_LDS_G = 0;
 template <int F> struct OddLds
 {
+    // per-wave LDS buffer: the exchange buffers of the transforms (XBUF) or eight rows of F x 64 samples for the transposition of the
+    // coalesced loads, whichever is larger
+    static constexpr int WBUF = (8 * 64 * F * 8 > XBUF) ? 8 * 64 * F * 8 : XBUF;
     static constexpr int TB = F * 16 * 64 * 8, TC = TB + 2048, TWD = TC + 4 * 3 * 64 * 8, TWE = TWD + 8192, NCO = TWE + 512,
-                         XB = NCO + 512, Q = XB + FFT_WAVES * XBUF, QTAIL = Q + 16 + Q_RING * 8, QCLAIM = QTAIL + 16, BYTES = QCLAIM + 16;
+                         XB = NCO + 512, Q = XB + FFT_WAVES * WBUF, QTAIL = Q + 16 + Q_RING * 8, QCLAIM = QTAIL + 16, BYTES = QCLAIM + 16;
     static_assert(XB == fft_odd_table_floats(F) * 4, "odd table image size");
     static_assert(BYTES <= 160 * 1024, "LDS");
 };
@@ -837,10 +844,10 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
     const f2v *twe = reinterpret_cast<const f2v *>(smem + L::TWE);
     const f2v *ncob = reinterpret_cast<const f2v *>(smem + L::NCO);
     (void)ncob;
-    char *xb = smem + L::XB + wid * XBUF;
+    char *xb = smem + L::XB + wid * L::WBUF;
     // x[p][row]: after the transposition below, sample F (64 row + lane) + p of the block = x_p[64 row + lane].  It is LOADED
     // coalesced -- piece p of row r = the 64 samples F 64 r + 64 p + lane, 512 contiguous bytes per instruction -- and brought into
-    // the in-lane order through the wave's LDS buffer, four rows at a time (phase_transpose).  The first form of this kernel loaded
+    // the in-lane order through the wave's LDS buffer, eight rows at a time (phase_transpose).  The first form of this kernel loaded
     // the F samples of a lane directly (8 bytes per lane, 24 apart): every instruction then touched all 12 lines of a row, three
     // times the address work of the texture unit, and the kernel ran 1.16 ms where the selecting store takes 0.76
     // (profiles/r04_odd_decimation.txt).  int16 input: the raw pair sits in .x until it is used.
@@ -858,14 +865,14 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
     };
     // coalesced pieces -> phase streams, in place: row r's F pieces are written side by side (sample 64 j + lane of the row at
     // byte (64 j + lane) ISZ) and read back as the lane's own F consecutive samples (F lane + p).  The reads are F ISZ bytes
-    // apart: 6 (3) dwords, conflict-free over 32 lanes.  Four rows per round (4 x 1536 B of the 8.8 KB buffer).
+    // apart: 6 (3) dwords, conflict-free over 32 lanes.  Eight rows per round (the wave's buffer is 12 KB in this kernel).
     auto phase_transpose = [&]() {
         constexpr int ROWB = 64 * F * ISZ;
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 4)
+        for (int r0 = 0; r0 < 16; r0 += 8)
         {
 #pragma unroll
-            for (int r = r0; r < r0 + 4; r++)
+            for (int r = r0; r < r0 + 8; r++)
 #pragma unroll
                 for (int p = 0; p < F; p++)
                 {
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
             // LDS instructions in order; the other exchanges of this file cannot be proven alias-free and keep their order.)
             asm volatile("" ::: "memory"); // (required here, not IF_FIR_FFT_LDS_FENCE's choice)
 #pragma unroll
-            for (int r = r0; r < r0 + 4; r++)
+            for (int r = r0; r < r0 + 8; r++)
 #pragma unroll
                 for (int p = 0; p < F; p++)
                 {
@@ -1308,9 +1315,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         blk = (wid < act_waves) ? (int64_t)blockIdx.x * act_waves + wid : nblocks;
     }
     const unsigned voff = (unsigned)lane * 8u;
-    // (end game: from this global group on; groups are handed out in global order, so a workgroup whose current group has come
-    // this far is in the launch's last round or two)
-    const int64_t endgame_from = (nblocks_main + FFT_WAVES - 1) / FFT_WAVES - (int64_t)gridDim.x * ((diag & 8192) ? 2 : 1);
     while (blk < nblocks)
     {
         FFT_STAMP(0);
@@ -1420,7 +1424,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         exchange2(r, xb, lane);
         FFT_STAMP(4);
         int64_t blk_next = blk + 1;
-        bool endgame = false;
         if (static_map)
         {
             blk_next = blk + static_stride;
@@ -1429,12 +1432,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         {
             // taken here: the block's own rows have all landed and the next block's are not issued yet, so the wait
             // behind the (rare) global atomic inside drains nothing
-            // End game (round 4, development bits 4096 / 8192 = the last 1 / 2 groups per workgroup): a wave that takes its next
-            // block HERE, in the middle of the current one, can end up holding one and a half blocks while a wave that asks a
-            // moment later gets nothing and leaves -- the waves of a launch end over a spread of two block times.  In the end
-            // game the take is deferred until the current block is stored (no prefetch for that block, but whoever is free takes it).
-            endgame = (diag & (4096 | 8192)) && (int64_t)(unsigned)(dq.cur_load() >> 32) >= endgame_from;
-            blk_next = endgame ? nblocks : queue_take(dq, simd, nblocks_main, nblocks);
+            // (Round 4 tried an "end game": during the launch's last one or two groups per workgroup the take was deferred until the
+            // current block was stored, so that no wave holds one and a half blocks while another leaves empty-handed.  Measured
+            // -0.4 % on 2^26 samples with one buffer, +0.1..0.5 % on rotating buffers and on 2^28-sample launches: removed,
+            // profiles/r04_end_game.txt.)
+            blk_next = queue_take(dq, simd, nblocks_main, nblocks);
         }
         const int64_t s0n = blk_next * L - OVL + n0 - in_shift;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
@@ -2224,7 +2226,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         FFT_STAMP(7);
         dbg_it++;
         loaded = next_fast;
-        blk = endgame ? queue_take(dq, simd, nblocks_main, nblocks) : blk_next;
+        blk = blk_next;
     }
 #ifndef IF_FIR_FFT_STAMPS
     if (dbg && lane == 0)
