@@ -728,7 +728,9 @@ def main():
         try:
             torch.cuda.empty_cache()
             for cname, forms in (("fir127_2p26", (("auto", fir.BACKEND_AUTO, 20, 5), ("direct", fir.BACKEND_HIP_DIRECT, 20, 5))),
-                                 ("fir1023_2p28", (("auto", fir.BACKEND_AUTO, 20, 5), ("tapsplit", fir.BACKEND_HIP_TAPSPLIT, 2, 1)))):
+                                 ("fir1023_2p28", (("auto", fir.BACKEND_AUTO, 20, 5), ("tapsplit", fir.BACKEND_HIP_TAPSPLIT, 2, 1))),
+                                 # (round 4: an odd decimation on its own kernel -- blocks of 3 x 1024 samples -- beside the BASELINE configs)
+                                 ("fir255_dec3_2p28", (("auto", fir.BACKEND_AUTO, 20, 5),))):
                 cfgs[cname] = {"workload": WORKLOADS[cname][3]}
                 for label, b, st, wu in forms:
                     cfgs[cname][label] = time_config(fir, cname, b, x, dev, stream, st, wu, names)
