@@ -140,6 +140,24 @@ __device__ __forceinline__ void fft16(cf (&v)[16])
     bfly4<INV>(y[3][0], y[3][1], y[3][2], y[3][3], v[3], v[7], v[11], v[15]);
 }
 
+// 8-point FFT, natural order in and out (one radix-2 stage with twiddles W8^a, two radix-4 butterflies): 28 packed instructions
+template <bool INV>
+__device__ __forceinline__ void fft8(cf (&v)[8])
+{
+    constexpr float R = 0.70710678118654752f;
+    cf u[4], d[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+    {
+        u[a] = v[a] + v[a + 4];
+        d[a] = v[a] - v[a + 4];
+    }
+    d[1] = cmul_s<INV>(d[1], (cf){R, -R});
+    d[3] = cmul_s<INV>(d[3], (cf){-R, -R});
+    bfly4<INV>(u[0], u[1], u[2], u[3], v[0], v[2], v[4], v[6]);
+    bfly4_crot<INV>(d[0], d[1], d[2], d[3], v[1], v[3], v[5], v[7]); // (d[2] carries W8^2 = -j: folded into the butterfly's adds)
+}
+
 // ---- twiddles in (cos, tan) form (round 4) ---------------------------------------------------------------------------------
 // A twiddle w = c (1 + j t) is kept as the pair E = (c, t).  x (1 + j t) is ONE packed FMA and a +- c u another, so a radix-4
 // butterfly whose inputs 1..3 carry twiddles w1, w2, w3 is 11 packed FMAs (3 twiddle multiplies + 8 adds = 14 instructions in the
@@ -722,26 +740,26 @@ __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16],
 constexpr int ODD_LDS_G = 0;
 template <int F> struct OddLds
 {
-    // per-wave LDS buffer: the exchange buffers of the transforms (XBUF) or eight rows of F x 64 samples for the transposition of the
-    // coalesced loads, whichever is larger
-    static constexpr int WBUF = (8 * 64 * F * 8 > XBUF) ? 8 * 64 * F * 8 : XBUF;
+    static constexpr int WBUF = XBUF; // per-wave LDS buffer: the exchange buffers of the transforms
     static constexpr int TB = F * 16 * 64 * 8, TC = TB + 2048, TWD = TC + 4 * 3 * 64 * 8, TWE = TWD + 8192, NCO = TWE + 512,
                          XB = NCO + 512, Q = XB + FFT_WAVES * WBUF, QTAIL = Q + 16 + Q_RING * 8, QCLAIM = QTAIL + 16, BYTES = QCLAIM + 16;
     static_assert(XB == fft_odd_table_floats(F) * 4, "odd table image size");
     static_assert(BYTES <= 160 * 1024, "LDS");
 };
 
-// forward 1024-point transform of v (reg[row] = x[64 row + lane]) into z (slot 4 i + k2', lane (g, k1): X[k0 + 16 k1 + 256 k2'],
-// k0 = 4 g + i): FFT16 over the rows (plain) -> Y^-1 -> FFT16 over mu1, inputs carry (W256^k0)^mu1 -> X^-1 -> 4-point DFT over
-// mu2, inputs carry (W1024^(k0 + 16 k1))^mu2
-__device__ __forceinline__ void forward_1024_tan(cf (&v)[16], cf (&z)[16], const f2v *tb, const f2v *tc, char *xb, int lane)
+// forward 1024-point transform of reg[row] = x[64 row + lane] into z (slot 4 i + k2', lane (g, k1): X[k0 + 16 k1 + 256 k2'],
+// k0 = 4 g + i): FFT16 over the rows (plain; done by the caller) -> Y^-1 -> FFT16 over mu1, inputs carry (W256^k0)^mu1 -> X^-1 ->
+// 4-point DFT over mu2, inputs carry (W1024^(k0 + 16 k1))^mu2
+// (v = the output of the first pass, the plain FFT16 over the rows, of the lane whose in-lane-order index lsrc = 4 mu1 + mu2 gave
+// wr_off = (lsrc & 3) XREG + (lsrc >> 2) XROW: the kernel runs that pass on its coalesced registers and lets every lane deliver
+// the column it happens to hold)
+__device__ __forceinline__ void forward_1024_tan(cf (&v)[16], cf (&z)[16], const f2v *tb, const f2v *tc, char *xb, int lane, int wr_off)
 {
     const int g = lane >> 4, m = lane & 15;
-    fft16<false>(v); // over mu0 -> k0; lane = 4 mu1 + mu2
     cf y[16];
     {
         // Y^-1: element k0 of lane 4 mu1 + mu2 -> lane (k0, mu2), slot mu1 (the addresses of inverse_tail256's Y, roles swapped)
-        char *wr = xb + (lane & 3) * XREG + (lane >> 2) * XROW;      // + k0*8
+        char *wr = xb + wr_off;                                      // + k0*8
         const int k0 = 4 * g + (m >> 2), low = m & 3;
         const char *rd = xb + low * XREG + k0 * 8;                   // + mu1*XROW
 #pragma unroll
@@ -785,7 +803,10 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
     using L = OddLds<F>;
     constexpr int ISZ = I16 ? 4 : 8;
     constexpr int LOUT = 1024 - 64 * OVLR, LIN = F * LOUT, OVL = F * 64 * OVLR;
-    constexpr bool LATE_LAST = NCO; // (the NCO's lane phasor and row table reads raise the pressure behind the inverse)
+    // phases whose refill with the next block's rows is issued behind the inverse instead of right after their transform (their
+    // registers would otherwise be live through the other phases' transforms and the inverse: with one phase late the instantiations
+    // without an NCO use 150-200 bytes of scratch)
+    constexpr int LATE = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const char *in = reinterpret_cast<const char *>(in_);
     const int lane = threadIdx.x & 63;
@@ -845,9 +866,8 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
     const f2v *ncob = reinterpret_cast<const f2v *>(smem + L::NCO);
     (void)ncob;
     char *xb = smem + L::XB + wid * L::WBUF;
-    // x[p][row]: after the transposition below, sample F (64 row + lane) + p of the block = x_p[64 row + lane].  It is LOADED
-    // coalesced -- piece p of row r = the 64 samples F 64 r + 64 p + lane, 512 contiguous bytes per instruction -- and brought into
-    // the in-lane order through the wave's LDS buffer, eight rows at a time (phase_transpose).  The first form of this kernel loaded
+    // x[p][row]: piece p of row r = the 64 samples F 64 r + 64 p + lane of the block, 512 contiguous bytes per load instruction (the
+    // in-lane order -- sample F (64 row + lane) + p -- only in the first block of a call).  The first form of this kernel loaded
     // the F samples of a lane directly (8 bytes per lane, 24 apart): every instruction then touched all 12 lines of a row, three
     // times the address work of the texture unit, and the kernel ran 1.16 ms where the selecting store takes 0.76
     // (profiles/r04_odd_decimation.txt).  int16 input: the raw pair sits in .x until it is used.
@@ -863,44 +883,22 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
                 x[p][r] = buf_load<IF_FIR_FFT_LOAD_AUX(0)>(srd, vo, so);
         }
     };
-    // coalesced pieces -> phase streams, in place: row r's F pieces are written side by side (sample 64 j + lane of the row at
-    // byte (64 j + lane) ISZ) and read back as the lane's own F consecutive samples (F lane + p).  The reads are F ISZ bytes
-    // apart: 6 (3) dwords, conflict-free over 32 lanes.  Eight rows per round (the wave's buffer is 12 KB in this kernel).
-    auto phase_transpose = [&]() {
-        constexpr int ROWB = 64 * F * ISZ;
+    // coalesced pieces -> phase streams WITHOUT a transposition of their own (the second form of this kernel had one, through LDS:
+    // 96 LDS instructions and 4 round trips a block).  Register column j of lane l holds row-sample 64 j + l = F l' + p' of every
+    // row, i.e. the column of in-lane-order lane l' = (64 j + l) / F of phase p' = (j + l) mod F (64 = 1 mod 3): the first pass
+    // of the 1024-point transform -- the FFT16 over the rows -- runs on the columns as they are; then every lane rotates its F
+    // columns by l mod F so that register column p holds phase p, and delivers it into the first transposition as lane
+    // l'_p = (64 ((p - l) mod F) + l) / F would have.
+    static_assert(F == 3, "column rotation written for three phases");
+    const int rot = lane % 3;
+    int wr_ph[F];
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 8)
-        {
-#pragma unroll
-            for (int r = r0; r < r0 + 8; r++)
-#pragma unroll
-                for (int p = 0; p < F; p++)
-                {
-                    char *wr = xb + (r - r0) * ROWB + (64 * p + lane) * ISZ;
-                    if constexpr (I16)
-                        *reinterpret_cast<float *>(wr) = x[p][r].x;
-                    else
-                        *reinterpret_cast<f2v *>(wr) = x[p][r];
-                }
-            // The lanes exchange data here, and for ONE lane a read at byte F ISZ lane + ISZ p never overlaps one of its own writes
-            // at ISZ lane + 64 ISZ p' (the difference is 8 mod 16): without a fence the compiler is free to move such a read past
-            // the next round's writes -- it did, the first build of this form filtered garbage.  (The hardware executes a wave's
-            // LDS instructions in order; the other exchanges of this file cannot be proven alias-free and keep their order.)
-            asm volatile("" ::: "memory"); // (required here, not IF_FIR_FFT_LDS_FENCE's choice)
-#pragma unroll
-            for (int r = r0; r < r0 + 8; r++)
-#pragma unroll
-                for (int p = 0; p < F; p++)
-                {
-                    const char *rd = xb + (r - r0) * ROWB + (F * lane + p) * ISZ;
-                    if constexpr (I16)
-                        x[p][r].x = *reinterpret_cast<const float *>(rd);
-                    else
-                        x[p][r] = *reinterpret_cast<const f2v *>(rd);
-                }
-            asm volatile("" ::: "memory");
-        }
-    };
+    for (int p = 0; p < F; p++)
+    {
+        const int lsrc = (64 * ((p - rot + 3) % 3) + lane) / 3;
+        wr_ph[p] = (lsrc & 3) * XREG + (lsrc >> 2) * XROW;
+    }
+    const int wr_std = (lane & 3) * XREG + (lane >> 2) * XROW;
     int64_t blk = queue_take(dq, simd, nblocks, nblocks);
     bool loaded = false;
     const unsigned voff = (unsigned)lane * 8u;
@@ -939,8 +937,30 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
                 inlane = true; // (this block was fetched in the lanes' own order: no transposition)
             }
         }
-        if (!inlane)
-            phase_transpose();
+        // first pass of the three 1024-point transforms on the register columns as loaded, then the column rotation
+#pragma unroll
+        for (int j = 0; j < F; j++)
+        {
+            cf v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = I16 ? cvt_i16(__float_as_uint(x[j][r].x)) : x[j][r];
+            fft16<false>(v);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                x[j][r] = v[r];
+        }
+        {
+            const bool r1 = !inlane && rot == 1, r2 = !inlane && rot == 2;
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0++)
+            {
+                const cf a0 = x[0][k0], a1 = x[1][k0], a2 = x[2][k0];
+                x[0][k0] = r1 ? a2 : r2 ? a1 : a0;
+                x[1][k0] = r1 ? a0 : r2 ? a2 : a1;
+                x[2][k0] = r1 ? a1 : r2 ? a0 : a2;
+            }
+        }
         int64_t blk_next = nblocks;
         bool next_fast = false;
         srd_t nsrd = make_srd(in, 0);
@@ -951,8 +971,8 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
             cf v[16], z[16];
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                v[r] = I16 ? cvt_i16(__float_as_uint(x[p][r].x)) : x[p][r];
-            forward_1024_tan(v, z, tb, tc, xb, lane);
+                v[r] = x[p][r];
+            forward_1024_tan(v, z, tb, tc, xb, lane, inlane ? wr_std : wr_ph[p]);
 #pragma unroll
             for (int sidx = 0; sidx < 16; sidx++)
             {
@@ -967,17 +987,17 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
                 next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
                 nsrd = make_srd(in + (next_fast ? s0n : 0) * ISZ, next_fast ? (N - s0n) * ISZ : 0);
             }
-            // this phase's 16 registers are dead: refill them with the next block's (the instantiations with an NCO issue the last
-            // two phases' loads behind the inverse: their store path would otherwise spill)
-            if (next_fast && !(LATE_LAST && p >= F - 2))
+            // this phase's 16 registers are dead: refill them with the next block's (the last LATE phases behind the inverse)
+            if (next_fast && p < F - LATE)
                 load_phase(nsrd, p);
         }
         cf c[16];
         inverse_dec4_tan(zacc, c, twe, twd, xb, lane);
-        if (LATE_LAST && next_fast)
+        if (next_fast)
         {
-            load_phase(nsrd, F - 2);
-            load_phase(nsrd, F - 1);
+#pragma unroll
+            for (int p = F - LATE; p < F; p++)
+                load_phase(nsrd, p);
         }
         const int64_t obase = blk * LOUT;
         // SPEC 3.2: output m = obase + 64 (mu0 - OVLR) + lane of the fs/F-rate tail is rotated by phasor(phi0 + delta m) = A(lane) B(row)
@@ -1122,8 +1142,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // fold + 2048-point inverse); 4 / 8 / 16 = the filter bank at that decimation
     // (1 = the decimate-by-4 tail keeping every sub-th output: decimation 8, 12, ..., 64; 3 = the decimate-by-2 tail doing the same:
     // decimation 6, 10, ..., 62)
-    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 8 || CHAN == 16) && DEC4),
-                  "decimating tails: 1, 2, 3, or the bank at 4, 8, 16");
+    // (9, round 4 = the bank at decimation 8 in its all-slots form: the eight slots of ONE parity from two 8-point transforms per group)
+    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 8 || CHAN == 9 || CHAN == 16) && DEC4),
+                  "decimating tails: 1, 2, 3, or the bank at 4, 8 (8: per channel, 9: all slots of a parity), 16");
+    static_assert(CHAN != 9 || !NCO, "the all-slots form serves channels on the slot grid");
     static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
     // 2 overlap rows (<= 129 taps, round 4): the full-rate pipeline only -- the decimating tails drop whole 64-output rows of the
     // fs/F-rate block (OVL_ROWS / 4, / 2, ...), which 128 samples are not
@@ -1131,14 +1153,14 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     // decimate-by-4 kernels (single channel incl. the multiples of 4, and the bank at decimation 4): twiddles in (cos, tan) form
     // on the inputs of passes 2 and 3 and of the small inverse (round 4); every other tail keeps round 3's form and tables
-    constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4);
+    constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4 || CHAN == 9); // (9: its own table images)
     // the full-rate pipeline the same way, forward and inverse (the inverse's twiddles already sat on the inputs of its passes)
     constexpr bool TANF = IF_FIR_FFT_TAN && !DEC4;
     constexpr int OVL = 64 * OVL_ROWS;
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
     const char *in = reinterpret_cast<const char *>(in_);
     constexpr int L = FFT_N - OVL;         // new input samples per block
-    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L; // outputs per block (per channel)
+    constexpr int LOUT = CHAN == 16 ? L / 16 : (CHAN == 8 || CHAN == 9) ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L; // outputs per block (per channel)
     constexpr int EARLY_GROUPS = IF_FIR_FFT_EARLY_GROUPS; // dec4: batches of next-block loads issued during pass 3
     constexpr int LAUX = IF_FIR_FFT_LOAD_AUX(OVL_ROWS); // cache policy of the row loads
     constexpr int EDGE_MIN = DEC4 ? IF_FIR_FFT_EDGE_MIN_DEC : IF_FIR_FFT_EDGE_MIN_FULL;
@@ -1197,7 +1219,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         for (int i = threadIdx.x; i < LDS_XB / 16; i += 512)
             dst[i] = src[i];
 #endif
-        if constexpr (CHAN == 16)
+        if constexpr (CHAN == 16 || CHAN == 9)
         {
             if (threadIdx.x < 16)
                 reinterpret_cast<float2 **>(smem + LDS_QPTR)[threadIdx.x] = chan.out[threadIdx.x];
@@ -1703,6 +1725,101 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             }
             }
             (void)vo128;
+        }
+        else if constexpr (CHAN == 9)
+        {
+            // ---- filter bank at decimation 8, ALL SLOTS OF ONE PARITY (round 4; tools/fft_model.py bank8_parity) ----
+            // Z_s(k2') = sum_a w_{k2'}[a] W16^(a s) G_q[a], q = (k2' - s) mod 2 (the per-channel form above).  For the slots of one parity,
+            // s = 2 sigma + par, W16^(a s) = W16^(a par) W8^(a sigma): with the factor W16^(a par) in the table (a second image for
+            // the odd slots, fft_build_tables bank_parity)
+            //     Z_s(0) = FFT8( w0 . G_par )[sigma],      Z_s(1) = FFT8( w1 . G_(1 - par) )[sigma]
+            // -- w0 and w1 are used ONCE each, so the 64 registers of the block turn into the 64 values Z_s(k2') (8 slots x 2 x 4 groups)
+            // in place.  (All 16 slots at once would need 128 live values: the other parity is a second launch.)  16 multiplies
+            // and two 8-point transforms per group serve eight channels: 88 packed instructions where the per-channel form spends
+            // 8 x 60.  The inverses follow two slots at a time exactly as in the per-channel form; every lane stores to its slot's
+            // buffer (pointer table in LDS, as in the 16-slot bank); slots nobody asked for are not inverted.
+            const int par = (int)chan.sub & 1; // (the launcher passes the parity in `sub`)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                cf t0[8], t1[8];
+                // (cos, tan) form: the inputs of this pass still carry b^n2, b = W4096^(k0 + 16 k1) (passes 1 and 2 as in the
+                // decimate-by-4 kernels).  t[a] b^a +- t[a + 8] b^(a + 8) = b^a (t[a] +- b^8 t[a + 8]): b^a sits in the table image,
+                // b^8 = c (1 + j t) is the second of the three first-stage entries of pass 3 -- 3 packed FMAs per pair
+                const cf e8 = tw1[(i * 3 + 1) * 64 + lane];
+#pragma unroll
+                for (int a8 = 0; a8 < 8; a8++)
+                {
+                    const cf u = r[phys(i, a8)], vb = tw_u<false>(r[phys(i, a8 + 8)], e8);
+                    t0[a8] = cmul_v<false>(tw_ac<false>(u, vb, e8), hp[(i * 16 + a8) * 64 + lane]);     // w0 . (b^a G_par W16^(a par)): first half of the image
+                    t1[a8] = cmul_v<false>(tw_ac<true>(u, vb, e8), hp[(i * 16 + 8 + a8) * 64 + lane]); // w1 . (b^a G_(1 - par) W16^(a par)): second half
+                }
+                fft8<false>(t0);
+                fft8<false>(t1);
+#pragma unroll
+                for (int sg = 0; sg < 8; sg++)
+                {
+                    r[phys(i, sg)] = t0[sg];     // Z_s(0), s = 2 sg + par
+                    r[phys(i, sg + 8)] = t1[sg]; // Z_s(1)
+                }
+            }
+            constexpr int MU0_FIRST = OVL_ROWS / 4;
+            constexpr int EARLY_B = I16 ? 3 : 1; // batches whose next-block rows are requested ahead of their inverse (no scratch)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+            {
+                // slots of this batch: sigma = 2 b, 2 b + 1
+                const unsigned want = (chan.mask16 >> (2 * (2 * b) + par)) & 1u, want1 = (chan.mask16 >> (2 * (2 * b + 1) + par)) & 1u;
+                const bool wanted = (want | want1) != 0u;
+                cf a[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++)
+                    {
+                        const cf z0 = r[phys(i, 2 * b + ch)], z1 = r[phys(i, 8 + 2 * b + ch)];
+                        a[4 * i + 2 * ch] = z0 + z1;
+                        a[4 * i + 2 * ch + 1] = cmul_v<true>(z0 - z1, twd[(i * 4 + 2) * 64 + lane]); // conj W512^(16 k1 + k0)
+                    }
+                auto refill = [&]() {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int ch = 0; ch < 2; ch++)
+                        {
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, 2 * b + ch));
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, 8 + 2 * b + ch));
+                        }
+                };
+                if (b < EARLY_B && next_fast)
+                    refill();
+                if (wanted)
+                {
+                    cf c[16];
+                    inverse_tail256(a, c, twe, xb, lane);
+                    // lane = 4 mu1 + 2 ch + mu2, slot mu0 -> y_s[32 mu0 + 2 mu1 + mu2], s = 2 (2 b + ch) + par.  Mix-down: the call
+                    // constant W16^(s rot_e) (16th roots: table entries 16..31) times (-1)^(s m), m = obase + 32 (..) + 2 mu1 + mu2
+                    // with obase even: the sign is (-1)^(s mu2)
+                    const int sl = 2 * (2 * b + ((lane >> 1) & 1)) + par;
+                    float2 *po = reinterpret_cast<float2 *const *>(smem + LDS_QPTR)[sl];
+                    cf wl = ncob[16 + ((sl * (int)chan.rot_e) & 15)];
+                    if ((sl & lane) & 1)
+                        wl = (cf){-wl.x, -wl.y};
+                    const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
+                    if (po != nullptr && !(diag & 2))
+                    {
+#pragma unroll
+                        for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                        {
+                            const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
+                            if (idx < M)
+                                __builtin_nontemporal_store(cmul_v<false>(c[mu0], wl), reinterpret_cast<cf *>(po) + idx);
+                        }
+                    }
+                }
+                if (b >= EARLY_B && next_fast)
+                    refill();
+            }
         }
         else if constexpr (CHAN == 8)
         {
@@ -2266,7 +2383,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 {
     auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN, ACC>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
-    constexpr int LOUT = CHAN == 16 ? L / 16 : CHAN == 8 ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L;
+    constexpr int LOUT = CHAN == 16 ? L / 16 : (CHAN == 8 || CHAN == 9) ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L;
     static DeviceSetup setup;
     int ncus = 0;
     {
@@ -2277,10 +2394,10 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     // DECN: the kernel runs at full rate over the N inputs (blocks, run queue, history as for D = 1) and keeps every
     // D-th output, the first one at full-rate index n0
     // (decimation 4 sub behind the decimate-by-4 tail, CHAN == 1: the tail runs at the fs/4 rate and keeps every sub-th output)
-    constexpr int F = CHAN == 16 ? 16 : CHAN == 8 ? 8 : (CHAN == 2 || CHAN == 3) ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
+    constexpr int F = CHAN == 16 ? 16 : (CHAN == 8 || CHAN == 9) ? 8 : (CHAN == 2 || CHAN == 3) ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
     ChanArgs ca = a.chan ? *a.chan : ChanArgs{};
-    ca.sub = CHAN == 1 ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : 1u;
-    const int64_t m_rate = DECN ? a.N : (a.M - 1) * (int64_t)ca.sub + 1;
+    ca.sub = CHAN == 1 ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : CHAN == 9 ? (ca.sub & 1u) /* the parity */ : 1u;
+    const int64_t m_rate = DECN ? a.N : CHAN == 9 ? a.M : (a.M - 1) * (int64_t)ca.sub + 1; // (CHAN 9: `sub` carries the slot parity)
     const int32_t n0_rate = DECN ? 0 : a.n0;
     const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
     if (nblocks <= 0)
@@ -2436,13 +2553,74 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             bool general = a.nco_word != 0;
             for (uint32_t c = 0; c < a.chan->count; c++)
                 general = general || (a.chan->bin[c] & 255u) || a.chan->pword[c] != (a.chan->bin[c] << 20);
-            switch ((a.in_i16 ? 2 : 0) | (general ? 1 : 0))
+            if (general)
+                return a.in_i16 ? launch_fft_t<ROWS, true, true, true, 8>(a) : launch_fft_t<ROWS, true, false, true, 8>(a);
+            // Channels on the slot grid.  A parity (even / odd slots) with at least four channels, none listed twice, runs the
+            // ALL-SLOTS form (round 4): one launch computes the eight slots of that parity from two 8-point transforms per group
+            // (2340 packed instructions a block whatever the count, against 1008 + 415 per channel) and stores the wanted ones; the
+            // other channels keep the per-channel form.  Up to three launches per call on the context's stream; only the first
+            // one writes the next call's history.  (Its two table images follow the bank's own: fft_tables_b.)
+            const ChanArgs &cin = *a.chan;
+            int npar[2] = {0, 0};
+            uint32_t seen = 0;
+            bool dup = false;
+            for (uint32_t c = 0; c < cin.count; c++)
             {
-            case 0: return launch_fft_t<ROWS, true, false, false, 8>(a);
-            case 1: return launch_fft_t<ROWS, true, false, true, 8>(a);
-            case 2: return launch_fft_t<ROWS, true, true, false, 8>(a);
-            default: return launch_fft_t<ROWS, true, true, true, 8>(a);
+                const uint32_t sl = cin.slot[c] & 15u;
+                dup = dup || ((seen >> sl) & 1u);
+                seen |= 1u << sl;
+                npar[sl & 1u]++;
             }
+            const bool slots_form = !dup && a.fft_tables_b && !(a.diag & 4096); // (diag 4096, development: per-channel form only)
+            bool first = true;
+            for (uint32_t par = 0; par < 2; par++)
+            {
+                if (!slots_form || npar[par] < 4)
+                    continue;
+                ChanArgs cs{};
+                cs.count = (uint32_t)npar[par];
+                cs.sub = par;
+                cs.rot_e = cin.abs0n0 & 15u;
+                cs.abs0n0 = cin.abs0n0;
+                for (uint32_t c = 0; c < cin.count; c++)
+                    if ((cin.slot[c] & 1u) == par)
+                    {
+                        cs.out[cin.slot[c] & 15u] = cin.out[c];
+                        cs.mask16 |= 1u << (cin.slot[c] & 15u);
+                    }
+                LaunchArgs p = a;
+                p.chan = &cs;
+                p.fft_tables = static_cast<const float *>(a.fft_tables_b) + (size_t)par * FFT_TABLE_FLOATS; // (the all-slots form's two images behind the bank's own)
+                if (!first)
+                    p.hist_out = nullptr;
+                const hipError_t e = a.in_i16 ? launch_fft_t<ROWS, true, true, false, 9>(p) : launch_fft_t<ROWS, true, false, false, 9>(p);
+                if (e != hipSuccess)
+                    return e;
+                first = false;
+            }
+            ChanArgs cl{};
+            for (uint32_t c = 0; c < cin.count; c++)
+            {
+                if (slots_form && npar[cin.slot[c] & 1u] >= 4)
+                    continue;
+                const uint32_t k = cl.count++;
+                cl.slot[k] = cin.slot[c];
+                for (int w = 0; w < 14; w++)
+                    cl.tw[k][w] = cin.tw[c][w];
+                cl.rot0[k][0] = cin.rot0[c][0];
+                cl.rot0[k][1] = cin.rot0[c][1];
+                cl.out[k] = cin.out[c];
+                cl.bin[k] = cin.bin[c];
+                cl.pword[k] = cin.pword[c];
+            }
+            cl.abs0n0 = cin.abs0n0;
+            if (!cl.count)
+                return hipSuccess;
+            LaunchArgs p = a;
+            p.chan = &cl;
+            if (!first)
+                p.hist_out = nullptr;
+            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 8>(p) : launch_fft_t<ROWS, true, false, false, 8>(p);
         }
         if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
             switch (ckey)
@@ -2622,7 +2800,7 @@ static void tan_fft16_entries(double th, float *out, int stride)
 //   [64 KB, 66 KB)  tw2[k1*16 + n2]            = W256^(n2*k1)
 //   [66 KB, 82 KB)  twd, twe: twiddles of the decimate-by-4 1024-point inverse
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale,
-                      float *tables /* FFT_TABLE_FLOATS floats */, int bank, int full_rate)
+                      float *tables /* FFT_TABLE_FLOATS floats */, int bank, int full_rate, int bank_parity)
 {
     const double PI2 = 6.283185307179586476925286766559;
     float *tw1 = tables, *hp = tables + 2 * 4096, *tw2 = tables + 4 * 4096;
@@ -2725,9 +2903,50 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                             re += h[0] * ct[e] - h[1] * st[e];
                             im += h[0] * st[e] + h[1] * ct[e];
                         }
-                        hp[2 * ((i * 16 + 8 * q + a8) * 64 + lane) + 0] = (float)re;
-                        hp[2 * ((i * 16 + 8 * q + a8) * 64 + lane) + 1] = (float)im;
+                        // bank_parity (round 4): the images of the ALL-SLOTS form (kernel, CHAN == 9), 1 = even slots, 2 = odd slots.
+                        // Its forward passes are the decimate-by-4 kernels' ((cos, tan) twiddles on the inputs of passes 2 and 3), so
+                        // the factor b^a, b = W4096^(k0 + 16 k1), that input a of pass 3 still carries is folded in here; odd slots:
+                        // also the slot twiddle's common factor W16^a, and the halves are exchanged -- first half: the factor of
+                        // w0 = G_1, second: G_0
+                        int half = q;
+                        if (bank_parity)
+                        {
+                            const int par = bank_parity - 1;
+                            const int e = (256 * a8 * par + a8 * ((4 * (lane / 16) + i) + 16 * (lane % 16))) & 4095; // W16^(a par) b^a
+                            const double gr = re * ct[e] - im * st[e], gi = re * st[e] + im * ct[e];
+                            re = gr;
+                            im = gi;
+                            half = par ? 1 - q : q;
+                        }
+                        hp[2 * ((i * 16 + 8 * half + a8) * 64 + lane) + 0] = (float)re;
+                        hp[2 * ((i * 16 + 8 * half + a8) * 64 + lane) + 1] = (float)im;
                     }
+#if IF_FIR_FFT_TAN
+        if (bank_parity)
+        {
+            // forward passes 2 and 3 (first stage) in (cos, tan) form, as in the decimate-by-4 image below; the 512-point
+            // inverse keeps its tables (twd, twe above)
+            for (int e = 0; e < 2 * 4096; e++)
+                tw1[e] = 0.0f;
+            for (int e = 0; e < 2 * 256; e++)
+                tw2[e] = 0.0f;
+            for (int i = 0; i < 4; i++)
+            {
+                for (int lane = 0; lane < 64; lane++)
+                {
+                    float all[30];
+                    tan_fft16_entries(-PI2 * (double)((4 * (lane / 16) + i) + 16 * (lane % 16)) / 4096.0, all, 1);
+                    for (int e = 0; e < 3; e++)
+                    {
+                        tw1[2 * ((i * 3 + e) * 64 + lane) + 0] = all[2 * e];
+                        tw1[2 * ((i * 3 + e) * 64 + lane) + 1] = all[2 * e + 1];
+                    }
+                }
+                for (int g = 0; g < 4; g++)
+                    tan_fft16_entries(-PI2 * (double)(4 * g + i) / 256.0, tw2 + 2 * (i * 60 + g), 4);
+            }
+        }
+#endif
         return;
     }
     if (bank == 16)

@@ -54,7 +54,7 @@ struct LaunchArgs
     int device;
     hipStream_t stream;
     const void *fft_tables; // device, FFT_TABLE_FLOATS floats (overlap-save backend) or nullptr
-    const void *fft_tables_b; // second partition's tables (3074..4096 taps) or nullptr
+    const void *fft_tables_b; // second partition's tables (3074..4096 taps); filter bank at decimation 8: the all-slots form's two images; or nullptr
     int in_shift;             // overlap-save kernel: the input is read delayed by this many samples (second partition)
     void *queue; // device, 32 bytes: ticket counters of the persistent kernels (words 0-3, zeroed by the launcher) + fault count
     int diag;  // development diagnostics for the FFT kernel (0 in production)
@@ -134,7 +134,7 @@ hipError_t launch_fft(const LaunchArgs &a);
 // bank = 8 / 16: the merged table of the filter bank at decimation 8 / 16 in place of H; full_rate (D != 4, no bank): the image of
 // the full-rate pipeline (D = 1, the selecting store) with its twiddles in (cos, tan) form -- the decimate-by-2 tails keep the plain one
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale, float *tables,
-                      int bank = 0, int full_rate = 0);
+                      int bank = 0, int full_rate = 0, int bank_parity = 0);
 
 // Odd decimations F x sub, F = 3 or 5 (round 4): blocks of F x 1024 input samples, F forward 1024-point transforms of the phase
 // streams and one inverse (fir_odd_kernel); *pOvlr = dropped 64-output rows of a block (2, 4 or 8).  False: no such tail (the

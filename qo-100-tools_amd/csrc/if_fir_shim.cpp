@@ -219,7 +219,9 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
 {
     if (ctx->d_fft_tables_bank)
         return 1;
-    float *tab = (float *)malloc(sizeof(float) * if_fir::FFT_TABLE_FLOATS);
+    // decimation 8: three images back to back -- the bank's own and the all-slots form's for the even and for the odd slots (round 4)
+    const size_t images = ctx->D == 8 ? 3 : 1;
+    float *tab = (float *)malloc(sizeof(float) * if_fir::FFT_TABLE_FLOATS * images);
     if (!tab)
     {
         set_err(ctx, "filter-bank tables: out of host memory");
@@ -229,11 +231,14 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
     const int bank = ctx->D == 8 ? 8 : 16; // (if_fir_channelizer_process_device: decimation 8 or 16 here)
     if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)bank,
                              ctx->in_i16 ? 0x1p-15 : 1.0, tab, bank);
+    for (size_t par = 0; par + 1 < images; par++)
+        if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)bank,
+                                 ctx->in_i16 ? 0x1p-15 : 1.0, tab + if_fir::FFT_TABLE_FLOATS * (par + 1), bank, 0, 1 + (int)par);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
-        e = hipMalloc(&ctx->d_fft_tables_bank, sizeof(float) * if_fir::FFT_TABLE_FLOATS);
+        e = hipMalloc(&ctx->d_fft_tables_bank, sizeof(float) * if_fir::FFT_TABLE_FLOATS * images);
     if (e == hipSuccess)
-        e = hipMemcpy(ctx->d_fft_tables_bank, tab, sizeof(float) * if_fir::FFT_TABLE_FLOATS, hipMemcpyHostToDevice);
+        e = hipMemcpy(ctx->d_fft_tables_bank, tab, sizeof(float) * if_fir::FFT_TABLE_FLOATS * images, hipMemcpyHostToDevice);
     free(tab);
     if (e != hipSuccess)
     {
@@ -676,6 +681,8 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
         a.chan = chan;
         if (ctx->D >= 8)
             a.fft_tables = ctx->d_fft_tables_bank;
+        if (ctx->D == 8) // (the all-slots form's two images)
+            a.fft_tables_b = static_cast<const float *>(ctx->d_fft_tables_bank) + if_fir::FFT_TABLE_FLOATS;
     }
     a.queue_base = &ctx->queue_base;
     a.queue_valid = &ctx->queue_valid;

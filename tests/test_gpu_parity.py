@@ -821,7 +821,7 @@ def test_uniform_filter_bank(fir, oracle, torch_cuda, t):
 
 @pytest.mark.parametrize("d,t,i16", [(16, 255, False), (16, 1023, False), (16, 127, False), (16, 511, True), (16, 2047, False),
                                       (8, 255, False), (8, 1023, False), (8, 63, False), (8, 511, True), (8, 2047, False)])
-def test_filter_bank_at_decimation_8_and_16(fir, oracle, torch_cuda, d, t, i16):
+def test_filter_bank_at_decimation_8_and_16(fir, oracle, torch_cuda, monkeypatch, d, t, i16):
     """the bank at decimation 16 = the rate of an fs/16-wide channel (the kernel computes ALL
     16 slots from one forward transform: the 16-way alias fold of slot s is output s of one 16-point transform per group)
     and at decimation 8 = 2x oversampled channels (per channel, two channels per 512-point inverse), DESIGN §3.7.  Every
@@ -829,6 +829,7 @@ def test_filter_bank_at_decimation_8_and_16(fir, oracle, torch_cuda, d, t, i16):
     float32 and int16 input, the run queue of a one-workgroup launch, all 16 slots and subsets (decimation 8: repeats and odd
     counts too), nothing written outside the wanted buffers."""
     torch = torch_cuda
+    monkeypatch.setenv("IF_FIR_DEBUG", "1")   # (the development launch 4096 below)
     taps = fir.bpf_design(t, 0.0, 0.02 if d == 16 else 0.04)
     n = 400_011 if t <= 255 else 150_013
     if i16:
@@ -843,7 +844,13 @@ def test_filter_bank_at_decimation_8_and_16(fir, oracle, torch_cuda, d, t, i16):
     refs = {s: oracle.fir_nco_f64(taps, x, d, (s << 28) & 0xFFFFFFFF) for s in range(16)}
     subsets = ((list(range(16)), 0), ([5, 0, 15, 8, 3, 10, 1, 14], 0), ([7, 2], 2001))
     if d == 8:
-        subsets = ((list(range(16)), 0), ([5, 0, 15, 8, 3, 10, 3], 0), ([7], 2001))
+        # round 4: a parity (even / odd slots) with >= 4 channels, no slot twice, runs the ALL-SLOTS form (two 8-point transforms
+        # per group give the eight slots of that parity; the rest keep the per-channel form: up to three launches a call)
+        subsets = ((list(range(16)), 0), ([5, 0, 15, 8, 3, 10, 3], 0), ([7], 2001),
+                   ([1, 5, 9, 13, 2], 0),                       # odd slots all-slots + one even channel per-channel
+                   ([0, 2, 4, 6, 8, 10, 12, 14], 2001),         # even slots, one-workgroup grid (run queue)
+                   ([3, 1, 15, 13, 11, 9, 7, 5, 0, 4], 0),      # all odd slots + two even ones
+                   ([14, 3, 8, 6, 0], 1004096))                 # (development launch 4096: per-channel form although 4 even)
     with fir.IfFir(taps, d, n, dev=True) as f:
         if i16:
             f.set_input_format(fir.INPUT_I16)

@@ -2,7 +2,7 @@
 """fbank_bench.py — uniform filter bank (if_fir_channelizer_process_device) against the same channels
 computed one at a time (if_fir_set_nco contexts): time per pass over a 2^log2n-sample wideband stream, whole-output
 comparison of every channel, one JSON line.
-usage: python tools/fbank_bench.py [channels=8] [log2n=28] [taps=255] [decimation=4] [freq]   (decimation 4: 4x oversampled fs/16
+usage: python tools/fbank_bench.py [channels=8] [log2n=28] [taps=255] [decimation=4] [freq] [tuning=N]   (decimation 4: 4x oversampled fs/16
 channels; 16: the channel rate, all 16 slots from one forward transform, round 3; "freq" (decimation 8, round 4): the channels sit
 at arbitrary centres on the fs/4096 grid -- if_fir_channelizer_process_device_freq -- instead of on slots)"""
 import json
@@ -21,8 +21,11 @@ def main():
     log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 28
     taps_n = int(sys.argv[3]) if len(sys.argv) > 3 else 255
     dec = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-    freq = len(sys.argv) > 5 and sys.argv[5] == "freq"
+    freq = "freq" in sys.argv[5:]
+    tuning = [int(a[7:]) for a in sys.argv[5:] if a.startswith("tuning=")]   # e.g. tuning=1004096: decimation 8 without the all-slots form
     n = 1 << log2n
+    if tuning:
+        os.environ["IF_FIR_DEBUG"] = "1"
     fir = g.load_pkg().if_fir
     torch.cuda.set_device(0)
     taps = fir.bpf_design(taps_n, 0.0, 0.03 if dec == 4 else 0.02)
@@ -36,6 +39,8 @@ def main():
         return f.channelizer_process_device(slots, x.data_ptr(), ptrs, n)
     x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
     with fir.IfFir(taps, dec, 0, dev=True) as f:
+        if tuning:
+            f.set_tuning(tuning[0])
         m = f.out_count(n)
         outs = [torch.empty(2 * m, dtype=torch.float32, device="cuda") for _ in range(nch)]
         torch.cuda.synchronize()

@@ -362,6 +362,49 @@ if __name__ == "__main__":
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# decimation-8 bank, ALL SLOTS OF ONE PARITY (round 4): s = 2 sigma + par, W16^(a s) = W16^(a par) W8^(a sigma), so
+#     Z_s(0) = FFT8_a( w0[a] . G_par[a] W16^(a par) )[sigma]        Z_s(1) = FFT8_a( w1[a] . G_(1-par)[a] W16^(a par) )[sigma]
+# -- each of w0, w1 is used once: the block's 64 registers become the 64 values Z_s(k2') in place.  Checked against the
+# per-channel sums of bank8 above.
+def bank8_parity_z(x, h, par):
+    lane = np.arange(64)
+    g, m = lane // 16, lane % 16
+    H = np.fft.fft(h, N)
+    p3 = forward(x)
+    t = np.zeros_like(p3)
+    for i in range(4):
+        t[16 * i:16 * i + 16] = np.fft.ifft(p3[16 * i:16 * i + 16], axis=0)
+    G = np.zeros((64, 64), dtype=np.complex128)
+    for i in range(4):
+        for q in range(2):
+            for a in range(8):
+                G[16 * i + 8 * q + a] = W(16, a * q) * sum(H[(4 * g + i) + 16 * m + 256 * (q + 2 * j)] * W(8, a * j) for j in range(8))
+    worst = 0.0
+    for i in range(4):
+        w0 = np.array([t[16 * i + a] + t[16 * i + a + 8] for a in range(8)])
+        w1 = np.array([t[16 * i + a] - t[16 * i + a + 8] for a in range(8)])
+        img0 = np.array([G[16 * i + 8 * par + a] * W(16, a * par) for a in range(8)])          # first half of the parity image
+        img1 = np.array([G[16 * i + 8 * (1 - par) + a] * W(16, a * par) for a in range(8)])    # second half
+        z0 = np.fft.fft(w0 * img0, axis=0)
+        z1 = np.fft.fft(w1 * img1, axis=0)
+        for sg in range(8):
+            s = 2 * sg + par
+            for k2p, z in ((0, z0), (1, z1)):
+                q = (k2p - s) % 2
+                ref = sum((w0, w1)[k2p][a] * W(16, a * s) * G[16 * i + 8 * q + a] for a in range(8))
+                worst = max(worst, np.max(np.abs(ref - z[sg])))
+    return worst
+
+
+def main_bank8_parity():
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    h = rng.standard_normal(255)
+    for par in (0, 1):
+        print("bank8 parity %d: Z by 8-point transforms vs per-channel sums, max |diff|" % par, bank8_parity_z(x, h, par))
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # decimate-by-2 variant (round 3): fold the 2 aliases (k2 = k2' + 8 j, k2' in 0..7) and run a 2048-point inverse
 #   k' = k0 + 16*k1 + 256*k2'                              m' = mu2 + 8*mu1 + 128*mu0    (mu2 in 0..7)
 #   A: 8-point iDFT over k2' -> slot (i, mu2); twiddle conj W2048^((16*k1 + k0)*mu2)
