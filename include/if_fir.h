@@ -156,7 +156,9 @@ uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOu
  * The context's streaming state (history, decimation phase, sample index) is shared
  * by all channels.  ulChannels 1..16, slots 0..15: any subset, repeats allowed (decimation 16: each slot at most once);
  * ppDevOut[c]: 16-byte aligned device buffers of if_fir_out_count() samples each.  Asynchronous on the context's stream
- * like if_fir_process_device. */
+ * like if_fir_process_device.  (Decimation 8, no NCO on the context: four or more channels on even -- or on odd -- slots, no
+ * slot listed twice, are computed together from one pair of 8-point transforms per group, whatever their number; a call is then
+ * up to three kernel launches on the context's stream.  Results do not depend on the route beyond float32 rounding.) */
 uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots,
                                           const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples,
                                           uint64_t *pullOutSamples);
