@@ -9,11 +9,12 @@
  *                  stage of the block queue (tests/test_gpu_parity.py)
  *   1000 + bits    diagnostic launches of the overlap-save kernel (IF_FIR_DEBUG=1): 1 skip the global loads, 2 skip the
  *                  stores, 16 every wave fetches the same block, 32 static block map, 64 one wave per SIMD
- *   1000000 + bits the same with room for more bits (round 3): 4 + (n << 12) late start of the second wave per SIMD,
- *                  8 / 128 cache-line touches ahead of the next block group, ...  (DESIGN.md §3.4); 256 no tail phase in
- *                  short launches; 512 the waves of workgroup 0 count a queue fault and leave as if their bounded wait had
+ *   1000000 + bits the same with room for more bits (round 3; bits 4, 8, 128 belonged to experiments that are closed and
+ *                  removed); 256 no tail phase in short launches; 512 the waves of workgroup 0 count a queue fault and leave as if their bounded wait had
  *                  expired: blocks stay unwritten and if_fir_synchronize must report it (the fault path's test);
- *                  2048 (round 4) the queue's tail phase in launches of up to 16 two-wave rounds
+ *                  2048 (round 4) the queue's tail phase in launches of up to 16 two-wave rounds; 4096 (round 4) the filter
+ *                  bank at decimation 8 without the all-slots form: every channel through the per-channel form (same results
+ *                  to tolerance; A/B timing and tests)
  *   3000           decimation 2, 6, 10, ..., 62 through the full-rate kernel + selecting store instead of the decimate-by-2 tail (same results to
  *                  tolerance; A/B timing)
  *   4000           the next call fails before anything is launched (IF_FIR_DEBUG=1): lets tests reach callers' error paths

@@ -87,7 +87,7 @@ def main():
     print(json.dumps({
         "workload": "%s: %d channels x (%d-tap prototype, decimate-by-%d) from one 2^%d-sample stream" %
                     ("filter bank, channels at arbitrary centres (fs/4096 grid)" if freq else "uniform filter bank", nch, taps_n, dec, log2n),
-        "centres": centres if freq else None,
+        "centres": [round(c, 6) for c in centres] if freq else None,
         "bytes_per_input_sample": 8.0 + nch * 8.0 / dec,
         "slots": slots, "filter_bank_ms": round(ms_bank, 4), "one_channel_at_a_time_ms": round(ms_single, 4),
         "speedup": round(ms_single / ms_bank, 2),
