@@ -573,6 +573,9 @@ def main():
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the other single-GPU BASELINE configs timed after the headline (extra.configs)")
+    ap.add_argument("--extras-first", action="store_true",
+                    help="development: run the comparison measurements (extra.*) between the two halves of the conditioning, "
+                         "ahead of the timed steps, as up to round 3 (A/B of the order: profiles/r04_bench_order.txt)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -689,14 +692,13 @@ def main():
         cold_ms = c0.elapsed_time(c1) / args.steps
     cold_passes = (args.warmup + args.steps) if cold_ms is not None else 0
 
-    # ---- device conditioning and the comparison measurements, BEFORE the headline ---------------------------------
+    # ---- device conditioning BEFORE the headline ----------------------------------------------------------------------
     # After idling, the chip's power management first boosts, then clamps the clock hard for ~20 launches (10 ms) and
     # only then settles (profiles/r02a_kernel_trace_summary.json: 0.48-0.52 ms, then 0.60-0.67 ms, then 0.49 ms per
     # launch).  A filter in service streams continuously, so `value` is the settled rate: every rank first keeps its
-    # GPU busy for >= --condition-ms of device time: untimed passes of the very same step, then the other things this
-    # script measures anyway (direct form, the other BASELINE configs, a plain copy: reported under "extra", never part
-    # of `value`, and settled as well this way), then passes of the step again.  The W warm-up steps and the K timed
-    # steps follow unchanged.
+    # GPU busy for >= --condition-ms of device time with untimed passes of the very same step.  The W warm-up steps and the K
+    # timed steps follow unchanged; the other things this script measures (direct form, the other BASELINE configs, a plain
+    # copy, the filter bank: "extra", never part of `value`) come after them (measure_extras; --extras-first: the order up to round 3).
     extra = {}
     names = {1: "hip_direct", 2: "hip_tapsplit", 3: "hip_generic", 4: "hip_fft"}
     cond0 = torch.cuda.Event(enable_timing=True)
@@ -718,82 +720,91 @@ def main():
             cond_passes += 20
             done += 20
 
-    condition(args.condition_ms / 2, 20)   # first half ahead of the comparison measurements: they run settled as well
-    if args.backend == "auto" and f.get_backend() == fir.BACKEND_HIP_FFT and taps_n in (127, 255) \
-            and decim in (1, 4) and not i16 and not nco:
-        # the north_star's direct-form MAC kernel, timed beside the default overlap-save path (same buffers, same
-        # stream; not part of `value`)
-        f.set_backend(fir.BACKEND_HIP_DIRECT)
-        f.reset()
-        for _ in range(max(args.warmup, 100)):   # ~100 ms of its own launches: settled like the headline
-            step_stream()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(args.steps):
-            step_stream()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        dms = e0.elapsed_time(e1) / args.steps
-        extra["direct_form"] = {
-            "backend": "hip_direct", "kernel_ms": round(dms, 4), "msamples_per_s": round(n / dms / 1e3, 1),
-            "hbm_frac": round(algorithmic_bytes_per_sample(decim) * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "valu_tflops": round(algorithmic_flops_per_sample(taps_n, decim) * n / (dms * 1e-3) / 1e12, 2),
-            "note": "hand-written v_pk_fma_f32 direct form (bit-exact vs the oracle's float32 order model); power-limited"}
-        f.set_backend(fir.BACKEND_AUTO)
-        f.reset()
-    if world == 1 and not i16:
-        # what this very box's HBM does on plain streaming kernels (context for roofline.frac: the nominal peak is
-        # 8 TB/s, a device-to-device copy of the same buffer reaches about two thirds of it)
-        try:
-            xs = x[:min(x.numel(), 1 << 29)]
-            dst = torch.empty_like(xs)
-            cs0, cs1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for _ in range(3):
-                dst.copy_(xs)
-            cs0.record()
-            for _ in range(10):
-                dst.copy_(xs)
-            cs1.record()
+    condition(args.condition_ms / 2, 20)
+    def measure_extras():
+        # The comparison measurements (direct form, the other BASELINE configs, a plain copy, the filter bank: reported under
+        # "extra", never part of `value`).  Round 4: they run AFTER the timed steps.  They used to sit between the two halves of the
+        # conditioning; every second of full-power work ahead of the timed region costs the headline (same box, same library,
+        # driver form: 0.4806 ms with four comparison measurements ahead of it, 0.5103 ms with a fifth -- the chip is at its
+        # package power limit and warmer silicon leaks more; profiles/r04_bench_order.txt).  Each of them settles on ~100 ms of
+        # its own launches.
+        if args.backend == "auto" and f.get_backend() == fir.BACKEND_HIP_FFT and taps_n in (127, 255) \
+                and decim in (1, 4) and not i16 and not nco:
+            # the north_star's direct-form MAC kernel, timed beside the default overlap-save path (same buffers, same
+            # stream; not part of `value`)
+            f.set_backend(fir.BACKEND_HIP_DIRECT)
+            f.reset()
+            for _ in range(max(args.warmup, 100)):   # ~100 ms of its own launches: settled like the headline
+                step_stream()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(args.steps):
+                step_stream()
+            e1.record(stream)
             torch.cuda.synchronize()
-            copy_ms = cs0.elapsed_time(cs1) / 10
-            extra["hbm_copy_on_this_box"] = {"gbs": round(2 * xs.numel() * 4 / (copy_ms * 1e-3) / 1e9, 1),
-                                             "frac_of_peak": round(2 * xs.numel() * 4 / (copy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                             "note": "torch device-to-device copy of %d MiB (read + write bytes / time)" % (xs.numel() * 4 >> 20)}
-            del dst
-        except Exception as e:   # noqa: BLE001 - context only, never fatal
-            extra["hbm_copy_on_this_box"] = {"error": repr(e)}
-    if world == 1 and not args.no_extra_configs and args.workload == "fir255_dec4_2p28" and not args.channels:
-        # the other single-GPU BASELINE configs on the same resident stream: AUTO and the comparison form
-        # (direct form where the unrolled kernels exist, else the tap-split kernel of the north_star's wording)
-        cfgs = {}
-        try:
-            torch.cuda.empty_cache()
-            for cname, forms in (("fir127_2p26", (("auto", fir.BACKEND_AUTO, 20, 5), ("direct", fir.BACKEND_HIP_DIRECT, 20, 5))),
-                                 ("fir1023_2p28", (("auto", fir.BACKEND_AUTO, 20, 5), ("tapsplit", fir.BACKEND_HIP_TAPSPLIT, 2, 1))),
-                                 # (round 4: an odd decimation on its own kernel -- blocks of 3 x 1024 samples -- beside the BASELINE configs)
-                                 ("fir255_dec3_2p28", (("auto", fir.BACKEND_AUTO, 20, 5),))):
-                cfgs[cname] = {"workload": WORKLOADS[cname][3]}
-                for label, b, st, wu in forms:
-                    cfgs[cname][label] = time_config(fir, cname, b, x, dev, stream, st, wu, names)
-                # HBM bytes per launch of this config's AUTO kernel from the committed counter passes (another box)
-                rec = committed_traffic(cname, cfgs[cname]["auto"]["backend"])
-                if rec:
-                    cfgs[cname]["auto"]["traffic"] = rec.get("hbm_bytes_per_launch")
-                    cfgs[cname]["auto"]["traffic_over_algorithmic"] = round(
-                        rec.get("hbm_bytes_per_launch") / (algorithmic_bytes_per_sample(WORKLOADS[cname][1]) * (1 << WORKLOADS[cname][2])), 4)
-                    cfgs[cname]["auto"]["traffic_source"] = "profiles/traffic.json (%s, rocprofv3 FETCH_SIZE/WRITE_SIZE passes)" % rec.get("round")
-        except Exception as e:   # noqa: BLE001 - context only, never fatal
-            cfgs["error"] = repr(e)
-        extra["configs"] = cfgs
-        # 8 channels from one pass over the same resident stream (round 4: the all-slots form)
-        try:
-            torch.cuda.empty_cache()
-            if i16:
-                raise RuntimeError("float32 stream only")
-            extra["filter_bank"] = time_filter_bank(fir, x, dev, stream, log2n=WORKLOADS[args.workload][2])
-        except Exception as e:   # noqa: BLE001 - context only, never fatal
-            extra["filter_bank"] = {"error": repr(e)}
+            dms = e0.elapsed_time(e1) / args.steps
+            extra["direct_form"] = {
+                "backend": "hip_direct", "kernel_ms": round(dms, 4), "msamples_per_s": round(n / dms / 1e3, 1),
+                "hbm_frac": round(algorithmic_bytes_per_sample(decim) * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "valu_tflops": round(algorithmic_flops_per_sample(taps_n, decim) * n / (dms * 1e-3) / 1e12, 2),
+                "note": "hand-written v_pk_fma_f32 direct form (bit-exact vs the oracle's float32 order model); power-limited"}
+            f.set_backend(fir.BACKEND_AUTO)
+            f.reset()
+        if world == 1 and not i16:
+            # what this very box's HBM does on plain streaming kernels (context for roofline.frac: the nominal peak is
+            # 8 TB/s, a device-to-device copy of the same buffer reaches about two thirds of it)
+            try:
+                xs = x[:min(x.numel(), 1 << 29)]
+                dst = torch.empty_like(xs)
+                cs0, cs1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(3):
+                    dst.copy_(xs)
+                cs0.record()
+                for _ in range(10):
+                    dst.copy_(xs)
+                cs1.record()
+                torch.cuda.synchronize()
+                copy_ms = cs0.elapsed_time(cs1) / 10
+                extra["hbm_copy_on_this_box"] = {"gbs": round(2 * xs.numel() * 4 / (copy_ms * 1e-3) / 1e9, 1),
+                                                 "frac_of_peak": round(2 * xs.numel() * 4 / (copy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "note": "torch device-to-device copy of %d MiB (read + write bytes / time)" % (xs.numel() * 4 >> 20)}
+                del dst
+            except Exception as e:   # noqa: BLE001 - context only, never fatal
+                extra["hbm_copy_on_this_box"] = {"error": repr(e)}
+        if world == 1 and not args.no_extra_configs and args.workload == "fir255_dec4_2p28" and not args.channels:
+            # the other single-GPU BASELINE configs on the same resident stream: AUTO and the comparison form
+            # (direct form where the unrolled kernels exist, else the tap-split kernel of the north_star's wording)
+            cfgs = {}
+            try:
+                torch.cuda.empty_cache()
+                for cname, forms in (("fir127_2p26", (("auto", fir.BACKEND_AUTO, 20, 5), ("direct", fir.BACKEND_HIP_DIRECT, 20, 5))),
+                                     ("fir1023_2p28", (("auto", fir.BACKEND_AUTO, 20, 5), ("tapsplit", fir.BACKEND_HIP_TAPSPLIT, 2, 1))),
+                                     # (round 4: an odd decimation on its own kernel -- blocks of 3 x 1024 samples -- beside the BASELINE configs)
+                                     ("fir255_dec3_2p28", (("auto", fir.BACKEND_AUTO, 20, 5),))):
+                    cfgs[cname] = {"workload": WORKLOADS[cname][3]}
+                    for label, b, st, wu in forms:
+                        cfgs[cname][label] = time_config(fir, cname, b, x, dev, stream, st, wu, names)
+                    # HBM bytes per launch of this config's AUTO kernel from the committed counter passes (another box)
+                    rec = committed_traffic(cname, cfgs[cname]["auto"]["backend"])
+                    if rec:
+                        cfgs[cname]["auto"]["traffic"] = rec.get("hbm_bytes_per_launch")
+                        cfgs[cname]["auto"]["traffic_over_algorithmic"] = round(
+                            rec.get("hbm_bytes_per_launch") / (algorithmic_bytes_per_sample(WORKLOADS[cname][1]) * (1 << WORKLOADS[cname][2])), 4)
+                        cfgs[cname]["auto"]["traffic_source"] = "profiles/traffic.json (%s, rocprofv3 FETCH_SIZE/WRITE_SIZE passes)" % rec.get("round")
+            except Exception as e:   # noqa: BLE001 - context only, never fatal
+                cfgs["error"] = repr(e)
+            extra["configs"] = cfgs
+            # 8 channels from one pass over the same resident stream (round 4: the all-slots form)
+            try:
+                torch.cuda.empty_cache()
+                if i16:
+                    raise RuntimeError("float32 stream only")
+                extra["filter_bank"] = time_filter_bank(fir, x, dev, stream, log2n=WORKLOADS[args.workload][2])
+            except Exception as e:   # noqa: BLE001 - context only, never fatal
+                extra["filter_bank"] = {"error": repr(e)}
+    if args.extras_first:
+        measure_extras()
     condition(args.condition_ms, 20)       # and passes of the step itself right in front of the warm-up
     cond1.record(stream)
     torch.cuda.synchronize()
@@ -849,6 +860,8 @@ def main():
         if use_dist:
             dist.destroy_process_group()
         sys.exit(1)
+    if not args.extras_first:
+        measure_extras()
     if args.scatter and use_dist:
         cs = pkg.channel_shard
         root_inputs = None
