@@ -337,3 +337,77 @@ def test_mid_size_launches_with_the_tail_phase(fir, oracle, gpu_ok, n):
             os.environ.pop("IF_FIR_DEBUG", None)
         else:
             os.environ["IF_FIR_DEBUG"] = old
+
+
+@pytest.mark.parametrize("d,nch", [(8, 16), (8, 6), (16, 16)])
+def test_full_size_filter_bank(fir, oracle, gpu_ok, monkeypatch, d, nch):
+    """The filter bank at the headline size (2^28 samples of one wideband stream): EVERY output of every channel against (a) the
+    other form of the same bank -- decimation 8: the all-slots launches (round 4) against the per-channel form (development launch
+    4096) -- and (b), for two channels, a context that mixes, filters and decimates that one channel (if_fir_set_nco); windows of one
+    channel against the float64 NCO oracle; one call = two calls at an odd cut."""
+    import torch
+    torch.cuda.set_device(0)
+    monkeypatch.setenv("IF_FIR_DEBUG", "1")
+    n, t = 1 << 28, 255
+    taps = fir.bpf_design(t, 0.0, 0.02)
+    slots = list(range(16)) if nch == 16 else [1, 3, 5, 7, 9, 2]   # (6: five odd slots through the all-slots launch + an even one per channel)
+    with fir.IfFir(taps, d, 0, dev=True) as f:
+        x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+        m = f.out_count(n)
+        outs = [torch.empty(2 * m, dtype=torch.float32, device="cuda") for _ in slots]
+        torch.cuda.synchronize()
+        f.synth_device(x.data_ptr(), 0, n, 5)
+        assert f.get_backend() == fir.BACKEND_HIP_FFT
+        assert f.channelizer_process_device(slots, x.data_ptr(), [o.data_ptr() for o in outs], n) == m
+        f.synchronize()
+        assert f.debug_queue_faults() == 0
+        scale = max(o.abs().max().item() for o in outs)
+        assert scale > 0.05
+        if d == 8:
+            # (a) the per-channel form, every output of every channel
+            f.set_tuning(1000000 + 4096)
+            f.reset()
+            other = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+            for c, s in enumerate(slots):
+                assert f.channelizer_process_device([s], x.data_ptr(), [other.data_ptr()], n) == m
+                f.synchronize()
+                f.reset()
+                assert (outs[c] - other).abs().max().item() <= 2e-6 * scale, (d, s)
+            del other
+            f.set_tuning(0)
+        # split invariance: two calls at an odd cut (the all-slots launches carry the history and the mix-down phase like any call)
+        f.reset()
+        cut = (n // 2) + 12345
+        part = [torch.empty(2 * m, dtype=torch.float32, device="cuda") for _ in slots]
+        m1 = f.channelizer_process_device(slots, x.data_ptr(), [p.data_ptr() for p in part], cut)
+        tail = x[2 * cut:].clone()
+        torch.cuda.synchronize()
+        m2 = f.channelizer_process_device(slots, tail.data_ptr(), [p.data_ptr() + 8 * m1 for p in part], n - cut)
+        f.synchronize()
+        assert m1 + m2 == m
+        for c in range(len(slots)):
+            assert (outs[c] - part[c]).abs().max().item() <= 1e-6 * scale, (d, slots[c])
+        del part, tail
+    # (b) one context per channel, every output
+    ref = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+    for c in (1, len(slots) - 1):
+        s = slots[c]
+        with fir.IfFir(taps, d, 0) as f1:
+            f1.set_nco(s / 16.0 if s <= 8 else s / 16.0 - 1.0)
+            assert f1.process_device(x.data_ptr(), ref.data_ptr(), n) == m
+            f1.synchronize()
+        assert (outs[c] - ref).abs().max().item() <= 2e-6 * scale, (d, s)
+    # windows of one channel against the float64 NCO oracle
+    c = 2
+    s = slots[c]
+    w = 8192
+    for start in [0, (n // 3) & ~15, n - w]:
+        lo = max(0, start - (t - 1))
+        xs = x[2 * lo:2 * (start + w)].cpu().numpy()
+        hist = np.zeros(2 * (t - 1), dtype=np.float32)
+        hist[2 * (t - 1 - (start - lo)):] = xs[:2 * (start - lo)]
+        refw = oracle.fir_nco_f64(taps, xs[2 * (start - lo):], d, (s << 28) & 0xFFFFFFFF, hist, start)
+        first_out = (start + d - 1) // d
+        got = outs[c][2 * first_out:2 * first_out + refw.size].cpu().numpy()
+        l2, mx = oracle.err_metrics(got, refw)
+        assert l2 <= 1e-6 and mx <= 1e-6, (d, s, start, l2, mx)

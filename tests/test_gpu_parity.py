@@ -820,7 +820,8 @@ def test_uniform_filter_bank(fir, oracle, torch_cuda, t):
 
 
 @pytest.mark.parametrize("d,t,i16", [(16, 255, False), (16, 1023, False), (16, 127, False), (16, 511, True), (16, 2047, False),
-                                      (8, 255, False), (8, 1023, False), (8, 63, False), (8, 511, True), (8, 2047, False)])
+                                      (8, 255, False), (8, 1023, False), (8, 63, False), (8, 511, True), (8, 2047, False),
+                                      (8, 3073, False), (16, 3073, True)])   # (3073 taps: the longest prototype, 48 overlap rows)
 def test_filter_bank_at_decimation_8_and_16(fir, oracle, torch_cuda, monkeypatch, d, t, i16):
     """the bank at decimation 16 = the rate of an fs/16-wide channel (the kernel computes ALL
     16 slots from one forward transform: the 16-way alias fold of slot s is output s of one 16-point transform per group)
