@@ -1025,7 +1025,7 @@ def test_random_configurations_against_the_oracle(fir, oracle):
                             1026, 2047, 4096]))
         # (soak seeds also draw the decimations that run behind a tail keeping every sub-th output, round 3)
         d = int(rng.choice([1, 1, 2, 3, 4, 4, 5, 8, 16, 64] if "IF_FIR_TEST_SEED" not in os.environ else
-                           [1, 1, 2, 3, 4, 4, 5, 6, 8, 10, 12, 16, 20, 24, 28, 48, 62, 64]))
+                           [1, 1, 2, 3, 3, 4, 4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 24, 27, 28, 48, 62, 63, 64]))   # (round 4: 9, 15, 27, 63)
         n = int(rng.integers(1, 30_000))
         taps = (rng.standard_normal(t) / np.sqrt(t)).astype(np.float32)
         x = rng.standard_normal(2 * n).astype(np.float32)
@@ -1063,6 +1063,71 @@ def test_random_configurations_against_the_oracle(fir, oracle):
         done[names[b]] += 1
     if "IF_FIR_TEST_SEED" not in os.environ:   # (soak seeds draw the backends as they come; the default seed covers all four)
         assert all(v >= 3 for v in done.values()), done
+
+
+def test_random_filter_bank_configurations_against_the_oracle(fir, oracle, torch_cuda):
+    """Sweep of random filter-bank calls: decimation 4 / 8 / 16, random prototypes, random slot subsets (decimation 8:
+    repeats too -- the routing between the all-slots launches and the per-channel form follows the subset), channels at random
+    centres on the fs/4096 grid (decimation 8), a common fine offset (the context's NCO, decimation 8 / 16), float32 / int16, random
+    piece cuts.  Every channel within SPEC tolerance of the float64 NCO oracle; nothing written past a channel's outputs."""
+    torch = torch_cuda
+    rng = np.random.default_rng(int(os.environ.get("IF_FIR_TEST_SEED", "20261004")) + 17)   # other seeds: soak runs
+    kinds = {"slots4": 0, "slots8": 0, "slots16": 0, "freq8": 0, "nco": 0, "allslots": 0}
+    for case in range(40):
+        d = int(rng.choice([4, 8, 8, 8, 16]))
+        t = int(rng.choice([1, 2, 17, 63, 64, 65, 127, 255, 256, 257, 511, 777, 1023, 1025, 2047, 3073]))
+        n = int(rng.integers(1, 40_000))
+        taps = (rng.standard_normal(t) / np.sqrt(t)).astype(np.float32)
+        i16 = rng.random() < 0.3
+        x = rng.standard_normal(2 * n).astype(np.float32)
+        if i16:
+            xi = np.clip(np.round(x * 8000.0), -32768, 32767).astype(np.int16)
+            x = xi.astype(np.float32) * np.float32(2.0 ** -15)
+        freq = d == 8 and rng.random() < 0.3
+        nco = 0.0 if (d == 4 or freq or rng.random() < 0.7) else float(rng.uniform(-0.5, 0.5))
+        nch = int(rng.integers(1, 17))
+        if d == 16 or (d == 8 and rng.random() < 0.6):
+            slots = [int(v) for v in rng.permutation(16)[:nch]]                 # each slot once
+        else:
+            slots = [int(v) for v in rng.integers(0, 16, size=nch)]              # repeats allowed (decimation 4 / 8)
+        centres = [int(v) / 4096.0 for v in rng.integers(-2048, 2048, size=nch)]
+        cuts = sorted(set([0, n] + [int(c) & (~3 if i16 else ~0) for c in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))]))
+        xd = torch.from_numpy(xi if i16 else x).cuda()
+        with fir.IfFir(taps, d, n) as f:
+            if i16:
+                f.set_input_format(fir.INPUT_I16)
+            if nco:
+                f.set_nco(nco)
+            word = oracle.nco_phase_word(f.get_nco()) if nco else 0
+            parts = [[] for _ in range(nch)]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                m_exp = oracle.out_count(a, b - a, d)
+                outs = [torch.full((2 * m_exp + 8,), 3.0, dtype=torch.float32, device="cuda") for _ in range(nch)]
+                piece = xd[2 * a:2 * b].clone()
+                torch.cuda.synchronize()
+                ptrs = [o.data_ptr() for o in outs]
+                if freq:
+                    assert f.channelizer_process_device_freq(centres, piece.data_ptr(), ptrs, b - a) == m_exp
+                else:
+                    assert f.channelizer_process_device(slots, piece.data_ptr(), ptrs, b - a) == m_exp
+                f.synchronize()
+                for c in range(nch):
+                    o = outs[c].cpu().numpy()
+                    assert np.all(o[2 * m_exp:] == 3.0), (case, d, t, n, c)
+                    parts[c].append(o[:2 * m_exp])
+        for c in range(nch):
+            pw = oracle.nco_phase_word(centres[c]) if freq else ((slots[c] << 28) + word) & 0xFFFFFFFF
+            ref = oracle.fir_nco_f64(taps, x, d, pw)
+            got = np.concatenate(parts[c]) if parts[c] else np.zeros(0, np.float32)
+            assert got.shape == ref.shape
+            if ref.size and np.any(ref):
+                l2, mx = oracle.err_metrics(got, ref)
+                assert l2 <= TOL and mx <= TOL, (case, d, t, n, i16, nco, freq, slots, centres[c], cuts, l2, mx)
+        kinds["freq8" if freq else "nco" if nco else "slots%d" % d] += 1
+        if d == 8 and not freq and not nco and len(set(slots)) == nch and max(sum(1 for v in slots if v % 2 == p) for p in (0, 1)) >= 4:
+            kinds["allslots"] += 1
+    if "IF_FIR_TEST_SEED" not in os.environ:
+        assert all(v >= 2 for v in kinds.values()), kinds
 
 
 def test_contexts_on_concurrent_threads(fir, oracle):
