@@ -324,7 +324,7 @@ constexpr int LDS_QNCO = LDS_QPTR + 16 * 8; // bank tails with an NCO: the block
 constexpr int LDS_QTAIL = LDS_QNCO + FFT_WAVES * 8, LDS_QCLAIM = LDS_QTAIL + 16;
 // filter bank at decimation 8 (round 4): W16^(a s), s = 0..15, a = 0..7 (1 KB) and per channel the 16 row phasors of its mix-down
 // (CHAN_MAX x 16 entries), both computed by the workgroup at the start of the launch
-constexpr int LDS_W16T = LDS_QCLAIM + 16, LDS_ROWT = LDS_W16T + 128 * 8;
+constexpr int LDS_W16T = LDS_QCLAIM + 16, LDS_ROWT = LDS_W16T + 256 * 8; // (decimation 16, channels at any centre: W16^(n2 s), 256 entries)
 constexpr int FFT_LDS_BYTES = LDS_ROWT + CHAN_MAX * 16 * 8;
 static_assert(FFT_LDS_BYTES <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 
@@ -1143,9 +1143,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // (1 = the decimate-by-4 tail keeping every sub-th output: decimation 8, 12, ..., 64; 3 = the decimate-by-2 tail doing the same:
     // decimation 6, 10, ..., 62)
     // (9, round 4 = the bank at decimation 8 in its all-slots form: the eight slots of ONE parity from two 8-point transforms per group)
-    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 8 || CHAN == 9 || CHAN == 16) && DEC4),
-                  "decimating tails: 1, 2, 3, or the bank at 4, 8 (8: per channel, 9: all slots of a parity), 16");
+    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 8 || CHAN == 9 || CHAN == 16 || CHAN == 17) && DEC4),
+                  "decimating tails: 1, 2, 3, or the bank at 4, 8 (8: per channel, 9: all slots of a parity), 16 (16: all slots, 17: per channel)");
     static_assert(CHAN != 9 || !NCO, "the all-slots form serves channels on the slot grid");
+    static_assert(CHAN != 17 || !NCO, "channels at their own centres: no common offset on top");
     static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
     // 2 overlap rows (<= 129 taps, round 4): the full-rate pipeline only -- the decimating tails drop whole 64-output rows of the
     // fs/F-rate block (OVL_ROWS / 4, / 2, ...), which 128 samples are not
@@ -1160,7 +1161,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     constexpr int ISZ = I16 ? 4 : 8;       // bytes per input sample
     const char *in = reinterpret_cast<const char *>(in_);
     constexpr int L = FFT_N - OVL;         // new input samples per block
-    constexpr int LOUT = CHAN == 16 ? L / 16 : (CHAN == 8 || CHAN == 9) ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L; // outputs per block (per channel)
+    constexpr int LOUT = (CHAN == 16 || CHAN == 17) ? L / 16 : (CHAN == 8 || CHAN == 9) ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L; // outputs per block (per channel)
     constexpr int EARLY_GROUPS = IF_FIR_FFT_EARLY_GROUPS; // dec4: batches of next-block loads issued during pass 3
     constexpr int LAUX = IF_FIR_FFT_LOAD_AUX(OVL_ROWS); // cache policy of the row loads
     constexpr int EDGE_MIN = DEC4 ? IF_FIR_FFT_EDGE_MIN_DEC : IF_FIR_FFT_EDGE_MIN_FULL;
@@ -1224,13 +1225,18 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             if (threadIdx.x < 16)
                 reinterpret_cast<float2 **>(smem + LDS_QPTR)[threadIdx.x] = chan.out[threadIdx.x];
         }
-        if constexpr (CHAN == 8)
+        if constexpr (CHAN == 8 || CHAN == 17)
         {
             // slot twiddles W16^(a s) = exp(-j 2 pi a s / 16) and, per channel, the phasors of output rows 0..15 of a block:
-            // row k is 32 outputs = 256 input samples behind row 0
-            if (threadIdx.x < 128)
+            // row k is 32 outputs (decimation 16: 16 outputs) = 256 input samples behind row 0
+            if (CHAN == 8 && threadIdx.x < 128)
             {
                 const float2 w = nco_phasor(0u - ((((threadIdx.x >> 3) * (threadIdx.x & 7)) & 15u) << 28));
+                reinterpret_cast<cf *>(smem + LDS_W16T)[threadIdx.x] = (cf){w.x, w.y};
+            }
+            if (CHAN == 17 && threadIdx.x < 256) // [s * 16 + n2]
+            {
+                const float2 w = nco_phasor(0u - ((((threadIdx.x >> 4) * (threadIdx.x & 15)) & 15u) << 28));
                 reinterpret_cast<cf *>(smem + LDS_W16T)[threadIdx.x] = (cf){w.x, w.y};
             }
             if (threadIdx.x < 16u * chan.count)
@@ -1725,6 +1731,90 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             }
             }
             (void)vo128;
+        }
+        else if constexpr (CHAN == 17)
+        {
+            // ---- filter bank at decimation 16, every channel at its own centre bin (round 4; the decimation-8 general form below at
+            // the channel rate).  Centre bin B = 256 s + b: H_c(k) = H(k - B); with k = k_low + 256 k2 and k_low - b = kappa - 256 cy
+            //   Z_c(k_low) = sum_n2 t[n2] W16^(n2 s') G0^kappa[n2],  s' = s + cy,  G0[n2] = sum_k2 H(k_low + 256 k2) W16^(n2 k2)
+            // (t = the inputs of pass 3, G0 = the 16-slot bank's table, gathered from the lane that holds kappa); 256-point inverses,
+            // four channels at a time: lane = 4 mu1 + ch, slot mu0 -> y_ch[16 mu0 + mu1]
+            constexpr int MU0_FIRST = OVL_ROWS / 4;
+            const int nch = (int)chan.count;
+            const int lq = (lane >> 4) + 4 * (lane & 15); // k_low >> 2
+            const f2v *w16t = reinterpret_cast<const f2v *>(smem + LDS_W16T);
+            const f2v *rowt = reinterpret_cast<const f2v *>(smem + LDS_ROWT);
+            for (int cq = 0; cq < nch; cq += 4)
+            {
+                const bool last = cq + 4 >= nch; // the inputs of pass 3 die with the last four channels: refill with the next block
+                cf a[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ch++)
+                    {
+                        if (cq + ch >= nch) // fewer than four: empty quarters
+                        {
+                            a[4 * i + ch] = (cf){0.f, 0.f};
+                            continue;
+                        }
+                        const int cb = (int)chan.bin[cq + ch], b = cb & 255, s = cb >> 8; // wave-uniform
+                        const int ik = (i - b) & 3;                                      // table group of kappa (kappa % 4)
+                        const int d = lq - (b >> 2) - ((i < (b & 3)) ? 1 : 0);           // (k_low - b) >> 2, negative: a borrow from k2
+                        const int lk = d & 63;
+                        const int lane_k = ((lk & 3) << 4) | (lk >> 2);                  // the lane that holds kappa in group ik
+                        const int sp = (s + (d < 0 ? 1 : 0)) & 15;
+                        const f2v *g = hp + (ik * 16) * 64 + lane_k; // (+ n2 * 64 entries)
+                        const f2v *twp = w16t + sp * 16;
+                        cf z = cmul_v<false>(r[phys(i, 0)], g[0]);
+#pragma unroll
+                        for (int n2 = 1; n2 < 16; n2++)
+                            z = cmac_v(z, cmul_v<false>(r[phys(i, n2)], twp[n2]), g[n2 * 64]);
+                        a[4 * i + ch] = z;
+                    }
+                    if (last && i < EARLY_GROUPS && next_fast)
+                    {
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
+                    }
+                }
+                cf c[16];
+                inverse_tail256(a, c, twe, xb, lane);
+                if (last && next_fast)
+                {
+#pragma unroll
+                    for (int i = EARLY_GROUPS; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
+                }
+                // mix-down: output o = obase + 16 (mu0 - first) + mu1 of the call belongs to input sample abs0n0 + 16 o: a lane factor
+                // (exact 32-bit phase) times the channel's row phasor (256 input samples per row)
+                const int cs = lane & 3, mu1 = lane >> 2;
+                const int cl = (cq + cs < nch) ? cq + cs : nch - 1;
+                const int c1 = (cq + 1 < nch) ? cq + 1 : nch - 1, c2 = (cq + 2 < nch) ? cq + 2 : nch - 1, c3 = (cq + 3 < nch) ? cq + 3 : nch - 1;
+                float2 *po = cs == 0 ? chan.out[cq] : cs == 1 ? chan.out[c1] : cs == 2 ? chan.out[c2] : chan.out[c3];
+                const uint32_t pw = cs == 0 ? chan.pword[cq] : cs == 1 ? chan.pword[c1] : cs == 2 ? chan.pword[c2] : chan.pword[c3];
+                const int64_t o0 = obase + mu1;
+                const float2 pa = nco_phasor(0u - pw * (chan.abs0n0 + 16u * (uint32_t)o0));
+                const cf wl = {pa.x, pa.y};
+                const f2v *rowp = rowt + cl * 16;
+                if (cq + cs < nch && !(diag & 2))
+                {
+#pragma unroll
+                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    {
+                        const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
+                        if (idx < M)
+                        {
+                            const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
+                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                        }
+                    }
+                }
+            }
         }
         else if constexpr (CHAN == 9)
         {
@@ -2383,7 +2473,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 {
     auto kern = fir_fft_kernel<OVL_ROWS, DEC4, I16, NCO, CHAN, DECN, ACC>;
     constexpr int L = FFT_N - 64 * OVL_ROWS;
-    constexpr int LOUT = CHAN == 16 ? L / 16 : (CHAN == 8 || CHAN == 9) ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L;
+    constexpr int LOUT = (CHAN == 16 || CHAN == 17) ? L / 16 : (CHAN == 8 || CHAN == 9) ? L / 8 : (CHAN == 2 || CHAN == 3) ? L / 2 : DEC4 ? L / 4 : L;
     static DeviceSetup setup;
     int ncus = 0;
     {
@@ -2394,7 +2484,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     // DECN: the kernel runs at full rate over the N inputs (blocks, run queue, history as for D = 1) and keeps every
     // D-th output, the first one at full-rate index n0
     // (decimation 4 sub behind the decimate-by-4 tail, CHAN == 1: the tail runs at the fs/4 rate and keeps every sub-th output)
-    constexpr int F = CHAN == 16 ? 16 : (CHAN == 8 || CHAN == 9) ? 8 : (CHAN == 2 || CHAN == 3) ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
+    constexpr int F = (CHAN == 16 || CHAN == 17) ? 16 : (CHAN == 8 || CHAN == 9) ? 8 : (CHAN == 2 || CHAN == 3) ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
     ChanArgs ca = a.chan ? *a.chan : ChanArgs{};
     ca.sub = CHAN == 1 ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : CHAN == 9 ? (ca.sub & 1u) /* the parity */ : 1u;
     const int64_t m_rate = DECN ? a.N : CHAN == 9 ? a.M : (a.M - 1) * (int64_t)ca.sub + 1; // (CHAN 9: `sub` carries the slot parity)
@@ -2550,7 +2640,7 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
         {
             // slot form (chan->tw[] = W16^(a slot), a = 1..7) when every channel sits on the fs/16 grid and the context has no NCO;
             // the general form (chan->bin[] / pword[]: centre bin and mix-down word of a channel) otherwise
-            bool general = a.nco_word != 0;
+            bool general = a.nco_word != 0 || a.chan->general;
             for (uint32_t c = 0; c < a.chan->count; c++)
                 general = general || (a.chan->bin[c] & 255u) || a.chan->pword[c] != (a.chan->bin[c] << 20);
             if (general)
@@ -2622,6 +2712,8 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
                 p.hist_out = nullptr;
             return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 8>(p) : launch_fft_t<ROWS, true, false, false, 8>(p);
         }
+        if (a.D == 16 && a.chan->general) // every channel at its own centre (per channel; arrays indexed by channel)
+            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 17>(a) : launch_fft_t<ROWS, true, false, false, 17>(a);
         if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
             switch (ckey)
             {

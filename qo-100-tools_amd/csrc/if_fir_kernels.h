@@ -29,11 +29,13 @@ struct ChanArgs
     uint32_t mask16;         // decimation 16: bit s set = slot s is wanted (out[s] non-null)
     uint32_t rot_e;          // decimation 16: (abs0 + n0) mod 16: slot s is rotated by W16^(s rot_e) at this call's first output
     uint32_t sub;            // decimate-by-4 tail at decimation 4 * sub (single channel): keep every sub-th output (set by the launcher)
-    // decimation 8 (round 4): every channel has its own centre on the fs/4096 grid and its own mix-down frequency
+    // decimation 8 and 16 (round 4): every channel has its own centre on the fs/4096 grid and its own mix-down frequency
     uint32_t bin[CHAN_MAX];   // centre of the channel's filter: the prototype moved up by bin / 4096 cycles/sample (0..4095)
     uint32_t pword[CHAN_MAX]; // mix-down frequency as a 32-bit phase word (cycles/sample x 2^32), the context's NCO included:
-                              // output o of a call is rotated by exp(-j 2 pi pword (abs0n0 + 8 o) / 2^32)
+                              // output o of a call is rotated by exp(-j 2 pi pword (abs0n0 + D o) / 2^32)
     uint32_t abs0n0;          // absolute index (mod 2^32) of the input sample this call's first output belongs to
+    uint32_t general;         // 1: channels at their own centres (if_fir_channelizer_process_device_freq): bin / pword / out are indexed
+                              // by CHANNEL at every decimation (decimation 16 otherwise indexes by slot)
 };
 
 struct LaunchArgs

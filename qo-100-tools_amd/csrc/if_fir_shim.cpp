@@ -661,7 +661,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
     {
         // mix-down phase of every channel at this call's first output: exp(-j 2 pi slot (consumed + n0) / 16)
         // (decimation 16: the arrays are indexed by slot, all 16 are filled)
-        const bool slots16 = ctx->D == 16;
+        const bool slots16 = ctx->D == 16 && !chan->general; // (channels at their own centres: indexed by channel, no slot phases)
         const uint32_t entries = slots16 ? 16u : chan->count;
         for (uint32_t c = 0; c < entries; c++)
         {
@@ -723,7 +723,7 @@ IF_FIR_API uint8_t if_fir_process_device(if_fir_ctx_t *pCtx, const void *pDevIn,
 // Uniform filter bank (BUILD-DEFINED): channel c = the context's real prototype taps applied after a
 // mix-down by pulSlots[c]/16 cycles/sample, decimated by 4 -- the same result as ulChannels contexts with
 // if_fir_set_nco(slot/16), from ONE pass over the input (one forward transform per block, one small inverse per channel).
-// pdFreq != nullptr (if_fir_channelizer_process_device_freq, decimation 8): channel c is centred at pdFreq[c] cycles/sample
+// pdFreq != nullptr (if_fir_channelizer_process_device_freq, decimation 8 or 16): channel c is centred at pdFreq[c] cycles/sample
 // instead of on a slot
 static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots, const double *pdFreq,
                                const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples, uint64_t *pullOutSamples)
@@ -737,10 +737,10 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
         set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot (or centre) and output arrays", if_fir::CHAN_MAX);
         return 0;
     }
-    if (pdFreq && (pCtx->D != 8 || pCtx->nco_word))
+    if (pdFreq && ((pCtx->D != 8 && pCtx->D != 16) || pCtx->nco_word))
     {
-        set_err(pCtx, "if_fir_channelizer_process_device_freq: needs a context with decimation 8 and no NCO (every channel carries "
-                      "its own centre frequency)");
+        set_err(pCtx, "if_fir_channelizer_process_device_freq: needs a context with decimation 8 or 16 and no NCO (every channel "
+                      "carries its own centre frequency)");
         return 0;
     }
     if ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || (pCtx->D == 4 && (pCtx->ctaps || pCtx->nco_word)) ||
@@ -757,6 +757,7 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
     }
     if_fir::ChanArgs chan{};
     chan.count = ulChannels;
+    chan.general = pdFreq ? 1u : 0u;
     for (uint32_t c = 0; c < ulChannels; c++)
     {
         if (pdFreq)
