@@ -1143,8 +1143,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // (1 = the decimate-by-4 tail keeping every sub-th output: decimation 8, 12, ..., 64; 3 = the decimate-by-2 tail doing the same:
     // decimation 6, 10, ..., 62)
     // (9, round 4 = the bank at decimation 8 in its all-slots form: the eight slots of ONE parity from two 8-point transforms per group)
-    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 8 || CHAN == 9 || CHAN == 16 || CHAN == 17) && DEC4),
-                  "decimating tails: 1, 2, 3, or the bank at 4, 8 (8: per channel, 9: all slots of a parity), 16 (16: all slots, 17: per channel)");
+    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 5 || CHAN == 8 || CHAN == 9 || CHAN == 16 || CHAN == 17) && DEC4),
+                  "decimating tails: 1, 2, 3, or the bank at 4 (4: slots, 5: any centre), 8 (8: per channel, 9: all slots of a parity), 16 (16: all slots, 17: per channel)");
+    static_assert(CHAN != 5 || !NCO, "channels at their own centres: no common offset on top");
     static_assert(CHAN != 9 || !NCO, "the all-slots form serves channels on the slot grid");
     static_assert(CHAN != 17 || !NCO, "channels at their own centres: no common offset on top");
     static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
@@ -1154,7 +1155,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     // decimate-by-4 kernels (single channel incl. the multiples of 4, and the bank at decimation 4): twiddles in (cos, tan) form
     // on the inputs of passes 2 and 3 and of the small inverse (round 4); every other tail keeps round 3's form and tables
-    constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4 || CHAN == 9); // (9: its own table images)
+    constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4 || CHAN == 5 || CHAN == 9); // (9: its own table images)
     // the full-rate pipeline the same way, forward and inverse (the inverse's twiddles already sat on the inputs of its passes)
     constexpr bool TANF = IF_FIR_FFT_TAN && !DEC4;
     constexpr int OVL = 64 * OVL_ROWS;
@@ -1225,7 +1226,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             if (threadIdx.x < 16)
                 reinterpret_cast<float2 **>(smem + LDS_QPTR)[threadIdx.x] = chan.out[threadIdx.x];
         }
-        if constexpr (CHAN == 8 || CHAN == 17)
+        if constexpr (CHAN == 8 || CHAN == 17 || CHAN == 5)
         {
             // slot twiddles W16^(a s) = exp(-j 2 pi a s / 16) and, per channel, the phasors of output rows 0..15 of a block:
             // row k is 32 outputs (decimation 16: 16 outputs) = 256 input samples behind row 0
@@ -2182,6 +2183,85 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     buf_store(csrd, voff, (mu0 - MU0_FIRST) * 512, cmul_v<false>(c[mu0], wl));
             }
         }
+        else if constexpr (CHAN == 5)
+        {
+            // ---- filter bank at decimation 4, every channel at its own centre bin (round 4) ---------------------------------------
+            // The slot form above with the table entries of kappa (k_low - b = kappa - 256 cy, gathered from the lane that holds kappa)
+            // and the slot s' = s + cy:  Z_c(k_low, q) = sum_m0 y[q][m0] W16^(m0 s') G^kappa[m0][(q - s') mod 4].  The table holds
+            // G' = b_kappa^m0 G (the factor the first stage owes, folded in for the lane that owns the entry); this lane's data owe
+            // b_klow^m0 = b_kappa^m0 W4096^(m0 b) W16^(-m0 cy), and W16^(m0 s') W16^(-m0 cy) = W16^(m0 s): the factor beside the table is
+            // the wave-uniform W4096^(m0 B), B = 256 s + b (host, chan.tw) -- the lanes differ only in WHICH entry they read.
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                cf t[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    t[j] = r[phys(i, j)];
+                static_assert(CHAN != 5 || TAN, "the general form at decimation 4 is written for the (cos, tan) image");
+                const cf e1 = tw1[(i * 3 + 0) * 64 + lane], e2 = tw1[(i * 3 + 1) * 64 + lane], e3 = tw1[(i * 3 + 2) * 64 + lane];
+#pragma unroll
+                for (int m0 = 0; m0 < 4; m0++)
+                    bfly4_tw<false>(t[m0], t[m0 + 4], t[m0 + 8], t[m0 + 12], e1, e2, e3, r[phys(i, m0)], r[phys(i, m0 + 4)],
+                                    r[phys(i, m0 + 8)], r[phys(i, m0 + 12)]);
+            }
+            constexpr int MU0_FIRST = OVL_ROWS / 4;
+            const int nch = (int)chan.count;
+            const int lq = (lane >> 4) + 4 * (lane & 15); // k_low >> 2
+            const f2v *rowt = reinterpret_cast<const f2v *>(smem + LDS_ROWT);
+            for (int ch = 0; ch < nch; ch++)
+            {
+                const bool last = (ch == nch - 1); // the y values die with the last channel: refill with the next block
+                const int cb = (int)chan.bin[ch], b = cb & 255, s = cb >> 8; // wave-uniform
+                const cf w1 = {chan.tw[ch][0], chan.tw[ch][1]}, w2 = {chan.tw[ch][2], chan.tw[ch][3]},
+                         w3 = {chan.tw[ch][4], chan.tw[ch][5]};
+                cf z[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int ik = (i - b) & 3;                            // table group of kappa (kappa % 4)
+                    const int d = lq - (b >> 2) - ((i < (b & 3)) ? 1 : 0); // (k_low - b) >> 2, negative: a borrow from k2
+                    const int lk = d & 63;
+                    const int lane_k = ((lk & 3) << 4) | (lk >> 2);        // the lane that holds kappa in group ik
+                    const int sp = s + (d < 0 ? 1 : 0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                    {
+                        const f2v *g = hp + (ik * 16 + ((q - sp) & 3)) * 64 + lane_k; // + m0 * 256 entries
+                        cf acc = cmul_v<false>(r[phys(i, 4 * q)], g[0]);
+                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 1)], w1), g[256]);
+                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 2)], w2), g[512]);
+                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 3)], w3), g[768]);
+                        z[4 * i + q] = acc;
+                    }
+                    if (last && i < EARLY_GROUPS && next_fast)
+                    {
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
+                    }
+                }
+                cf c[16];
+                inverse_dec4_tan(z, c, twe, twd, xb, lane);
+                if (last && next_fast)
+                {
+#pragma unroll
+                    for (int i = EARLY_GROUPS; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
+                }
+                // mix-down: output o = obase + 64 (mu0 - first) + lane of the call belongs to input sample abs0n0 + 4 o: a lane factor
+                // (exact 32-bit phase) times the channel's row phasor (256 input samples per row)
+                const float2 pa = nco_phasor(0u - chan.pword[ch] * (chan.abs0n0 + 4u * (uint32_t)(obase + lane)));
+                const cf wl = {pa.x, pa.y};
+                const f2v *rowp = rowt + ch * 16;
+                const srd_t csrd = make_srd(chan.out[ch] + obase, (diag & 2) ? 0 : (M - obase) * 8);
+#pragma unroll
+                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    buf_store(csrd, voff, (mu0 - MU0_FIRST) * 512, cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST])));
+            }
+        }
         else if constexpr (DEC4)
         {
             // ---- pass 3, multiply by H/4096, fold the 4 aliases: z(i, k2') = sum_j Y(i, k2' + 4j) ------------------
@@ -2722,6 +2802,8 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             case 2: return launch_fft_t<ROWS, true, true, false, 16>(a);
             default: return launch_fft_t<ROWS, true, true, true, 16>(a);
             }
+        if (a.chan->general) // decimation 4, every channel at its own centre
+            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 5>(a) : launch_fft_t<ROWS, true, false, false, 5>(a);
         return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 4>(a) : launch_fft_t<ROWS, true, false, false, 4>(a);
     }
     if (a.D == 2 && !a.no_fold) // frequency-domain fold + 2048-point inverse (round 3)

@@ -723,7 +723,7 @@ IF_FIR_API uint8_t if_fir_process_device(if_fir_ctx_t *pCtx, const void *pDevIn,
 // Uniform filter bank (BUILD-DEFINED): channel c = the context's real prototype taps applied after a
 // mix-down by pulSlots[c]/16 cycles/sample, decimated by 4 -- the same result as ulChannels contexts with
 // if_fir_set_nco(slot/16), from ONE pass over the input (one forward transform per block, one small inverse per channel).
-// pdFreq != nullptr (if_fir_channelizer_process_device_freq, decimation 8 or 16): channel c is centred at pdFreq[c] cycles/sample
+// pdFreq != nullptr (if_fir_channelizer_process_device_freq, decimation 4, 8 or 16): channel c is centred at pdFreq[c] cycles/sample
 // instead of on a slot
 static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots, const double *pdFreq,
                                const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples, uint64_t *pullOutSamples)
@@ -737,9 +737,9 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
         set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot (or centre) and output arrays", if_fir::CHAN_MAX);
         return 0;
     }
-    if (pdFreq && ((pCtx->D != 8 && pCtx->D != 16) || pCtx->nco_word))
+    if (pdFreq && ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || pCtx->nco_word))
     {
-        set_err(pCtx, "if_fir_channelizer_process_device_freq: needs a context with decimation 8 or 16 and no NCO (every channel "
+        set_err(pCtx, "if_fir_channelizer_process_device_freq: needs a context with decimation 4, 8 or 16 and no NCO (every channel "
                       "carries its own centre frequency)");
         return 0;
     }
@@ -774,6 +774,12 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
             chan.bin[c] = (uint32_t)(llround(pdFreq[c] * 4096.0) & 4095);
             chan.pword[c] = (uint32_t)(int64_t)llround(pdFreq[c] * 4294967296.0);
             chan.out[c] = (float2 *)ppDevOut[c];
+            for (int m0 = 1; m0 < 4; m0++) // decimation 4: W4096^(m0 bin), the wave-uniform factor beside the gathered table entry
+            {
+                const double a = -2.0 * M_PI * (double)((m0 * chan.bin[c]) & 4095u) / 4096.0;
+                chan.tw[c][2 * (m0 - 1) + 0] = (float)cos(a);
+                chan.tw[c][2 * (m0 - 1) + 1] = (float)sin(a);
+            }
             continue;
         }
         if (pulSlots[c] > 15 || (ullSamples && !ppDevOut[c]) || ((uintptr_t)ppDevOut[c] & 15))

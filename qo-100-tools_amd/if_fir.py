@@ -283,7 +283,7 @@ class IfFir:
         return int(m.value)
 
     def channelizer_process_device_freq(self, centres, dev_in, dev_outs, samples):
-        """if_fir_channelizer_process_device_freq(): channel c centred at centres[c] cycles/sample (decimation 8 or 16)."""
+        """if_fir_channelizer_process_device_freq(): channel c centred at centres[c] cycles/sample (decimation 4, 8 or 16)."""
         k = len(centres)
         fc = (ctypes.c_double * k)(*[float(v) for v in centres])
         po = (ctypes.c_void_p * k)(*[ctypes.c_void_p(int(p)) for p in dev_outs])

@@ -932,10 +932,11 @@ def test_filter_bank_with_a_common_fine_offset(fir, oracle, torch_cuda, d, i16):
 
 
 @pytest.mark.parametrize("t,i16,d", [(255, False, 8), (1023, False, 8), (127, True, 8), (511, False, 8),
-                                     (255, False, 16), (1023, True, 16), (63, False, 16), (2047, False, 16)])
+                                     (255, False, 16), (1023, True, 16), (63, False, 16), (2047, False, 16),
+                                     (255, False, 4), (127, True, 4), (1023, False, 4), (3073, False, 4)])
 def test_filter_bank_channels_at_arbitrary_centre_frequencies(fir, oracle, torch_cuda, t, i16, d):
     """Round 4: channels at ARBITRARY centres from one pass (decimation 8, and 16 = the channel rate, four channels per
-    small inverse): the prototype moved up by the multiple
+    small inverse; and 4, one 1024-point inverse per channel): the prototype moved up by the multiple
     of fs/4096 nearest to the wanted centre (a shift of the overlap-save transform's bins: per lane another table row, the
     lanes rotated), mixed down by the exact centre.  Centres ON the grid: every channel against the float64 NCO oracle at that
     frequency = what C contexts with if_fir_set_nco(f_c) compute (also checked against one such context on the GPU).  Centres
@@ -1009,8 +1010,8 @@ def test_filter_bank_channels_at_arbitrary_centre_frequencies(fir, oracle, torch
         f.set_nco(0.01)
         with pytest.raises(fir.IfFirError, match="no NCO"):
             f.channelizer_process_device_freq([0.1], xd.data_ptr(), [out.data_ptr()], 16)
-    with fir.IfFir(taps, 4, n) as f:
-        with pytest.raises(fir.IfFirError, match="decimation 8 or 16"):
+    with fir.IfFir(taps, 2, n) as f:
+        with pytest.raises(fir.IfFirError, match="decimation 4, 8 or 16"):
             f.channelizer_process_device_freq([0.1], xd.data_ptr(), [xd.data_ptr()], 16)
 
 
@@ -1069,14 +1070,14 @@ def test_random_configurations_against_the_oracle(fir, oracle):
 def test_random_filter_bank_configurations_against_the_oracle(fir, oracle, torch_cuda):
     """Sweep of random filter-bank calls: decimation 4 / 8 / 16, random prototypes, random slot subsets (decimation 8:
     repeats too -- the routing between the all-slots launches and the per-channel form follows the subset), channels at random
-    centres on the fs/4096 grid (decimation 8 / 16), a common fine offset (the context's NCO, decimation 8 / 16), float32 / int16, random
+    centres on the fs/4096 grid (decimation 4 / 8 / 16), a common fine offset (the context's NCO, decimation 8 / 16), float32 / int16, random
     piece cuts.  Every channel within SPEC tolerance of the float64 NCO oracle; nothing written past a channel's outputs."""
     torch = torch_cuda
     rng = np.random.default_rng(int(os.environ.get("IF_FIR_TEST_SEED", "20261004")) + 17)   # other seeds: soak runs
-    schedule = ["slots4", "slots8", "slots16", "freq8", "freq16", "nco8", "nco16", "allslots"]   # every form in turn, the rest random
-    for case in range(40):
+    schedule = ["slots4", "slots8", "slots16", "freq4", "freq8", "freq16", "nco8", "nco16", "allslots"]   # every form in turn, the rest random
+    for case in range(45):
         kind = schedule[case % len(schedule)]
-        d = 4 if kind == "slots4" else 16 if kind.endswith("16") else 8
+        d = 4 if kind.endswith("4") else 16 if kind.endswith("16") else 8
         t = int(rng.choice([1, 2, 17, 63, 64, 65, 127, 255, 256, 257, 511, 777, 1023, 1025, 2047, 3073]))
         n = int(rng.integers(1, 40_000))
         taps = (rng.standard_normal(t) / np.sqrt(t)).astype(np.float32)

@@ -3,7 +3,7 @@
 computed one at a time (if_fir_set_nco contexts): time per pass over a 2^log2n-sample wideband stream, whole-output
 comparison of every channel, one JSON line.
 usage: python tools/fbank_bench.py [channels=8] [log2n=28] [taps=255] [decimation=4] [freq] [tuning=N]   (decimation 4: 4x oversampled fs/16
-channels; 16: the channel rate, all 16 slots from one forward transform, round 3; "freq" (decimation 8 or 16, round 4): the channels sit
+channels; 16: the channel rate, all 16 slots from one forward transform, round 3; "freq" (decimation 4, 8 or 16, round 4): the channels sit
 at arbitrary centres on the fs/4096 grid -- if_fir_channelizer_process_device_freq -- instead of on slots)"""
 import json
 import os
