@@ -324,7 +324,7 @@ constexpr int LDS_QNCO = LDS_QPTR + 16 * 8; // bank tails with an NCO: the block
 constexpr int LDS_QTAIL = LDS_QNCO + FFT_WAVES * 8, LDS_QCLAIM = LDS_QTAIL + 16;
 // filter bank at decimation 8 (round 4): W16^(a s), s = 0..15, a = 0..7 (1 KB) and per channel the 16 row phasors of its mix-down
 // (CHAN_MAX x 16 entries), both computed by the workgroup at the start of the launch
-constexpr int LDS_W16T = LDS_QCLAIM + 16, LDS_ROWT = LDS_W16T + 256 * 8; // (decimation 16, channels at any centre: W16^(n2 s), 256 entries)
+constexpr int LDS_ROWT = LDS_QCLAIM + 16;
 constexpr int FFT_LDS_BYTES = LDS_ROWT + CHAN_MAX * 16 * 8;
 static_assert(FFT_LDS_BYTES <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     // decimate-by-4 kernels (single channel incl. the multiples of 4, and the bank at decimation 4): twiddles in (cos, tan) form
     // on the inputs of passes 2 and 3 and of the small inverse (round 4); every other tail keeps round 3's form and tables
-    constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4 || CHAN == 5 || CHAN == 9); // (9: its own table images)
+    constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4 || CHAN == 5 || CHAN == 8 || CHAN == 9 || CHAN == 16 || CHAN == 17); // (8, 9, 16, 17: the banks' own images)
     // the full-rate pipeline the same way, forward and inverse (the inverse's twiddles already sat on the inputs of its passes)
     constexpr bool TANF = IF_FIR_FFT_TAN && !DEC4;
     constexpr int OVL = 64 * OVL_ROWS;
@@ -1228,18 +1228,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         }
         if constexpr (CHAN == 8 || CHAN == 17 || CHAN == 5)
         {
-            // slot twiddles W16^(a s) = exp(-j 2 pi a s / 16) and, per channel, the phasors of output rows 0..15 of a block:
-            // row k is 32 outputs (decimation 16: 16 outputs) = 256 input samples behind row 0
-            if (CHAN == 8 && threadIdx.x < 128)
-            {
-                const float2 w = nco_phasor(0u - ((((threadIdx.x >> 3) * (threadIdx.x & 7)) & 15u) << 28));
-                reinterpret_cast<cf *>(smem + LDS_W16T)[threadIdx.x] = (cf){w.x, w.y};
-            }
-            if (CHAN == 17 && threadIdx.x < 256) // [s * 16 + n2]
-            {
-                const float2 w = nco_phasor(0u - ((((threadIdx.x >> 4) * (threadIdx.x & 15)) & 15u) << 28));
-                reinterpret_cast<cf *>(smem + LDS_W16T)[threadIdx.x] = (cf){w.x, w.y};
-            }
+            // per channel, the phasors of output rows 0..15 of a block: row k is 32 outputs (decimation 16: 16, decimation 4: 64) = 256
+            // input samples behind row 0
             if (threadIdx.x < 16u * chan.count)
             {
                 const float2 w = nco_phasor(0u - chan.pword[threadIdx.x >> 4] * 256u * (threadIdx.x & 15u));
@@ -1489,6 +1479,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             // Channel s = the prototype moved up by s/16 cycles/sample; decimating by 16 aliases every slot centre to DC.
             // Folded spectrum of ALL 16 slots from one 16-point transform per group:
             //   Z_s(k0, k1) = sum_k2 H((k2 - s) mod 16) Y(k2) = FFT16(t * G0)[s],  G0[n2] = sum_k2 H(k2) W16^(n2 k2) (host table)
+            // (round 4: the forward passes in (cos, tan) form; the b^n2 the inputs of this pass still carry is folded into the table)
 #pragma unroll
             for (int i = 0; i < 4; i++)
             {
@@ -1739,11 +1730,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             // the channel rate).  Centre bin B = 256 s + b: H_c(k) = H(k - B); with k = k_low + 256 k2 and k_low - b = kappa - 256 cy
             //   Z_c(k_low) = sum_n2 t[n2] W16^(n2 s') G0^kappa[n2],  s' = s + cy,  G0[n2] = sum_k2 H(k_low + 256 k2) W16^(n2 k2)
             // (t = the inputs of pass 3, G0 = the 16-slot bank's table, gathered from the lane that holds kappa); 256-point inverses,
-            // four channels at a time: lane = 4 mu1 + ch, slot mu0 -> y_ch[16 mu0 + mu1]
+            // four channels at a time: lane = 4 mu1 + ch, slot mu0 -> y_ch[16 mu0 + mu1].  The inputs still carry b_klow^n2 ((cos, tan)
+            // forward passes); the gathered entry carries b_kappa^n2, and b_klow^n2 W16^(n2 s') = b_kappa^n2 W4096^(n2 B): the factor
+            // beside the entry is wave-uniform (host, chan.tw, SGPRs), as in the decimation-8 general form.
             constexpr int MU0_FIRST = OVL_ROWS / 4;
             const int nch = (int)chan.count;
             const int lq = (lane >> 4) + 4 * (lane & 15); // k_low >> 2
-            const f2v *w16t = reinterpret_cast<const f2v *>(smem + LDS_W16T);
             const f2v *rowt = reinterpret_cast<const f2v *>(smem + LDS_ROWT);
             for (int cq = 0; cq < nch; cq += 4)
             {
@@ -1767,11 +1759,14 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         const int lane_k = ((lk & 3) << 4) | (lk >> 2);                  // the lane that holds kappa in group ik
                         const int sp = (s + (d < 0 ? 1 : 0)) & 15;
                         const f2v *g = hp + (ik * 16) * 64 + lane_k; // (+ n2 * 64 entries)
-                        const f2v *twp = w16t + sp * 16;
+                        (void)sp; // (s' = s + cy is absorbed: see below)
                         cf z = cmul_v<false>(r[phys(i, 0)], g[0]);
 #pragma unroll
                         for (int n2 = 1; n2 < 16; n2++)
-                            z = cmac_v(z, cmul_v<false>(r[phys(i, n2)], twp[n2]), g[n2 * 64]);
+                        {
+                            const cf tw = {chan.tw[cq + ch][2 * (n2 - 1)], chan.tw[cq + ch][2 * (n2 - 1) + 1]}; // W4096^(n2 B)
+                            z = cmac_v(z, cmul_s<false>(r[phys(i, n2)], tw), g[n2 * 64]);
+                        }
                         a[4 * i + ch] = z;
                     }
                     if (last && i < EARLY_GROUPS && next_fast)
@@ -1919,15 +1914,22 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             // Channel at slot s:  Z_s(k2') = sum_a w_{k2'}[a] W16^(a s) G_q[a],  q = (k2' - s) mod 2 (host table G, kernel
             // arguments W16^(a s)); 512-point inverse, two channels per small inverse (low = 2 ch + mu2):
             // lane = 4 mu1 + 2 ch + mu2, slot mu0 -> y_ch[32 mu0 + 2 mu1 + mu2]
+            // (cos, tan) form (round 4): the inputs of this pass still carry b^n2, b = W4096^(k0 + 16 k1);
+            // t[a] b^a +- t[a + 8] b^(a + 8) = b^a (t[a] +- b^8 t[a + 8]): b^8 = c (1 + j t) is applied here (three packed FMAs a pair), b^a is
+            // folded into the table for the lane that OWNS the entry (see the general form below for lanes that read another lane's)
+            static_assert(CHAN != 8 || TAN, "the decimation-8 bank is written for its (cos, tan) image");
 #pragma unroll
             for (int i = 0; i < 4; i++)
+            {
+                const cf e8 = tw1[(i * 3 + 1) * 64 + lane];
 #pragma unroll
                 for (int a8 = 0; a8 < 8; a8++)
                 {
-                    const cf u = r[phys(i, a8)], v = r[phys(i, a8 + 8)];
-                    r[phys(i, a8)] = u + v;
-                    r[phys(i, a8 + 8)] = u - v;
+                    const cf u = r[phys(i, a8)], vb = tw_u<false>(r[phys(i, a8 + 8)], e8);
+                    r[phys(i, a8)] = tw_ac<false>(u, vb, e8);
+                    r[phys(i, a8 + 8)] = tw_ac<true>(u, vb, e8);
                 }
+            }
             constexpr int MU0_FIRST = OVL_ROWS / 4;
             const int nch = (int)chan.count;
             if constexpr (!NCO)
@@ -2013,9 +2015,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             // group) k_low - b = kappa - 256 cy, so the lane needs the table entries of low index kappa -- group (i - b) mod 4, the
             // lanes rotated: a permutation, conflict-free -- for the slot s' = s + cy (tools/fft_model.py bank8_bins):
             //   Z_c(k2') = sum_a w_{k2'}[a] W16^(a s') G_q^kappa[a],  q = (k2' - s') mod 2
+            // The table entry of kappa carries b_kappa^a (folded in for its owner); this lane's data owe b_klow^a =
+            // b_kappa^a W4096^(a b) W16^(-a cy), and W16^(a s') W16^(-a cy) = W16^(a s): the factor beside the gathered entry is the
+            // WAVE-UNIFORM W4096^(a B), B = 256 s + b (host, chan.tw, in SGPRs as in the slot form) -- the lanes differ only in which
+            // entry they read.
             // k_low >> 2 = lane / 16 + 4 (lane % 16) in every group
             const int lq = (lane >> 4) + 4 * (lane & 15);
-            const f2v *w16t = reinterpret_cast<const f2v *>(smem + LDS_W16T);
             const f2v *rowt = reinterpret_cast<const f2v *>(smem + LDS_ROWT);
             for (int cp = 0; cp < nch; cp += 2)
             {
@@ -2043,15 +2048,14 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         const int par = sp & 1;
                         const f2v *g0 = hp + (ik * 16 + 8 * par) * 64 + lane_k;       // k2' = 0: q = s' & 1       (+ a * 64 entries)
                         const f2v *g1 = hp + (ik * 16 + 8 * (1 - par)) * 64 + lane_k; // k2' = 1: q = (1 - s') & 1
-                        const f2v *twp = w16t + sp * 8;
                         cf z0 = cmul_v<false>(r[phys(i, 0)], g0[0]);
                         cf z1 = cmul_v<false>(r[phys(i, 8)], g1[0]);
 #pragma unroll
                         for (int a8 = 1; a8 < 8; a8++)
                         {
-                            const cf tw = twp[a8];
-                            z0 = cmac_v(z0, cmul_v<false>(r[phys(i, a8)], tw), g0[a8 * 64]);
-                            z1 = cmac_v(z1, cmul_v<false>(r[phys(i, a8 + 8)], tw), g1[a8 * 64]);
+                            const cf tw = {chan.tw[c][2 * (a8 - 1)], chan.tw[c][2 * (a8 - 1) + 1]}; // W4096^(a B)
+                            z0 = cmac_v(z0, cmul_s<false>(r[phys(i, a8)], tw), g0[a8 * 64]);
+                            z1 = cmac_v(z1, cmul_s<false>(r[phys(i, a8 + 8)], tw), g1[a8 * 64]);
                         }
                         a[4 * i + 2 * ch] = z0 + z1;
                         a[4 * i + 2 * ch + 1] = cmul_v<true>(z0 - z1, twd[(i * 4 + 2) * 64 + lane]); // conj W512^(16 k1 + k0)
@@ -2729,7 +2733,7 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             // ALL-SLOTS form (round 4): one launch computes the eight slots of that parity from two 8-point transforms per group
             // (2340 packed instructions a block whatever the count, against 1008 + 415 per channel) and stores the wanted ones; the
             // other channels keep the per-channel form.  Up to three launches per call on the context's stream; only the first
-            // one writes the next call's history.  (Its two table images follow the bank's own: fft_tables_b.)
+            // one writes the next call's history.  (Even slots: the bank's own table image; odd slots: fft_tables_b.)
             const ChanArgs &cin = *a.chan;
             int npar[2] = {0, 0};
             uint32_t seen = 0;
@@ -2760,7 +2764,7 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
                     }
                 LaunchArgs p = a;
                 p.chan = &cs;
-                p.fft_tables = static_cast<const float *>(a.fft_tables_b) + (size_t)par * FFT_TABLE_FLOATS; // (the all-slots form's two images behind the bank's own)
+                p.fft_tables = par ? a.fft_tables_b : a.fft_tables; // (even slots: the bank's own image; odd slots: the image behind it)
                 if (!first)
                     p.hist_out = nullptr;
                 const hipError_t e = a.in_i16 ? launch_fft_t<ROWS, true, true, false, 9>(p) : launch_fft_t<ROWS, true, false, false, 9>(p);
@@ -2775,7 +2779,7 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
                     continue;
                 const uint32_t k = cl.count++;
                 cl.slot[k] = cin.slot[c];
-                for (int w = 0; w < 14; w++)
+                for (int w = 0; w < 30; w++)
                     cl.tw[k][w] = cin.tw[c][w];
                 cl.rot0[k][0] = cin.rot0[c][0];
                 cl.rot0[k][1] = cin.rot0[c][1];
@@ -2968,6 +2972,31 @@ static void tan_fft16_entries(double th, float *out, int stride)
     }
 }
 
+// the filter banks' forward passes 2 and 3 (first stage) in (cos, tan) form, as in the decimate-by-4 image (fft_build_tables)
+static void bank_tan_forward(float *tw1, float *tw2)
+{
+    const double PI2 = 6.283185307179586476925286766559;
+    for (int e = 0; e < 2 * 4096; e++)
+        tw1[e] = 0.0f;
+    for (int e = 0; e < 2 * 256; e++)
+        tw2[e] = 0.0f;
+    for (int i = 0; i < 4; i++)
+    {
+        for (int lane = 0; lane < 64; lane++)
+        {
+            float all[30];
+            tan_fft16_entries(-PI2 * (double)((4 * (lane / 16) + i) + 16 * (lane % 16)) / 4096.0, all, 1);
+            for (int e = 0; e < 3; e++)
+            {
+                tw1[2 * ((i * 3 + e) * 64 + lane) + 0] = all[2 * e];
+                tw1[2 * ((i * 3 + e) * 64 + lane) + 1] = all[2 * e + 1];
+            }
+        }
+        for (int g = 0; g < 4; g++)
+            tan_fft16_entries(-PI2 * (double)(4 * g + i) / 256.0, tw2 + 2 * (i * 60 + g), 4);
+    }
+}
+
 // Host side: twiddle and H tables in the kernel's LDS image order (float64 math, rounded once to float32).
 //   [0, 32 KB)      tw1[(rho*16+k0)*64 + lane] = W4096^((lane+64*rho)*k0)
 //   [32 KB, 64 KB)  hp [(i*16+k2)*64 + lane]   = FFT(taps)[(4*(lane/16)+i) + 16*(lane%16) + 256*k2] / 4096
@@ -3077,16 +3106,20 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                             re += h[0] * ct[e] - h[1] * st[e];
                             im += h[0] * st[e] + h[1] * ct[e];
                         }
-                        // bank_parity (round 4): the images of the ALL-SLOTS form (kernel, CHAN == 9), 1 = even slots, 2 = odd slots.
-                        // Its forward passes are the decimate-by-4 kernels' ((cos, tan) twiddles on the inputs of passes 2 and 3), so
-                        // the factor b^a, b = W4096^(k0 + 16 k1), that input a of pass 3 still carries is folded in here; odd slots:
-                        // also the slot twiddle's common factor W16^a, and the halves are exchanged -- first half: the factor of
-                        // w0 = G_1, second: G_0
+                        // Round 4: the bank's forward passes are the decimate-by-4 kernels' ((cos, tan) twiddles on the inputs of passes 2
+                        // and 3), so the factor b^a, b = W4096^(k0 + 16 k1), that input a of pass 3 still carries is folded in here.
+                        // This image serves the per-channel forms (CHAN == 8) and the all-slots form's even slots (CHAN == 9);
+                        // bank_parity = 1: the all-slots form's image for the ODD slots -- also the slot twiddle's common factor W16^a,
+                        // and the halves exchanged (first half: the factor of w0 = G_1, second: G_0)
                         int half = q;
-                        if (bank_parity)
                         {
-                            const int par = bank_parity - 1;
-                            const int e = (256 * a8 * par + a8 * ((4 * (lane / 16) + i) + 16 * (lane % 16))) & 4095; // W16^(a par) b^a
+                            const int par = bank_parity ? 1 : 0;
+#if IF_FIR_FFT_TAN
+                            const int eb = a8 * ((4 * (lane / 16) + i) + 16 * (lane % 16)); // b^a
+#else
+                            const int eb = 0;
+#endif
+                            const int e = (256 * a8 * par + eb) & 4095; // W16^(a par) b^a
                             const double gr = re * ct[e] - im * st[e], gi = re * st[e] + im * ct[e];
                             re = gr;
                             im = gi;
@@ -3096,30 +3129,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                         hp[2 * ((i * 16 + 8 * half + a8) * 64 + lane) + 1] = (float)im;
                     }
 #if IF_FIR_FFT_TAN
-        if (bank_parity)
-        {
-            // forward passes 2 and 3 (first stage) in (cos, tan) form, as in the decimate-by-4 image below; the 512-point
-            // inverse keeps its tables (twd, twe above)
-            for (int e = 0; e < 2 * 4096; e++)
-                tw1[e] = 0.0f;
-            for (int e = 0; e < 2 * 256; e++)
-                tw2[e] = 0.0f;
-            for (int i = 0; i < 4; i++)
-            {
-                for (int lane = 0; lane < 64; lane++)
-                {
-                    float all[30];
-                    tan_fft16_entries(-PI2 * (double)((4 * (lane / 16) + i) + 16 * (lane % 16)) / 4096.0, all, 1);
-                    for (int e = 0; e < 3; e++)
-                    {
-                        tw1[2 * ((i * 3 + e) * 64 + lane) + 0] = all[2 * e];
-                        tw1[2 * ((i * 3 + e) * 64 + lane) + 1] = all[2 * e + 1];
-                    }
-                }
-                for (int g = 0; g < 4; g++)
-                    tan_fft16_entries(-PI2 * (double)(4 * g + i) / 256.0, tw2 + 2 * (i * 60 + g), 4);
-            }
-        }
+        bank_tan_forward(tw1, tw2); // (the 512-point inverse keeps its tables: twd, twe above)
 #endif
         return;
     }
@@ -3139,9 +3149,21 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                         re += h[0] * ct[e] - h[1] * st[e];
                         im += h[0] * st[e] + h[1] * ct[e];
                     }
+#if IF_FIR_FFT_TAN
+                    {
+                        // (round 4) the b^n2, b = W4096^(k0 + 16 k1), that input n2 of pass 3 still carries ((cos, tan) forward passes)
+                        const int eb = (n2 * ((4 * (lane / 16) + i) + 16 * (lane % 16))) & 4095;
+                        const double gr = re * ct[eb] - im * st[eb], gi = re * st[eb] + im * ct[eb];
+                        re = gr;
+                        im = gi;
+                    }
+#endif
                     hp[2 * ((i * 16 + n2) * 64 + lane) + 0] = (float)re;
                     hp[2 * ((i * 16 + n2) * 64 + lane) + 1] = (float)im;
                 }
+#if IF_FIR_FFT_TAN
+        bank_tan_forward(tw1, tw2);
+#endif
         return;
     }
     if (D != 4)

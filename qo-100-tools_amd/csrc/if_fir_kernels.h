@@ -23,7 +23,7 @@ struct ChanArgs
 {
     uint32_t count;
     uint32_t slot[CHAN_MAX];
-    float tw[CHAN_MAX][14];  // decimation 4: W16^(m0 slot), m0 = 1..3 (re, im); decimation 8: W16^(a slot), a = 1..7
+    float tw[CHAN_MAX][30];  // W4096^(a bin), a = 1..15 (re, im); slots: bin = 256 slot, i.e. W16^(a slot).  Decimation 4 uses a = 1..3, 8: 1..7, 16 (per channel): all
     float rot0[CHAN_MAX][2]; // exp(-j 2 pi slot (abs0 + n0) / 16): mix-down phase at this call's first output
     float2 *out[CHAN_MAX];   // device, M samples each
     uint32_t mask16;         // decimation 16: bit s set = slot s is wanted (out[s] non-null)

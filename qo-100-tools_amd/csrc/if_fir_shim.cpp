@@ -219,8 +219,9 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
 {
     if (ctx->d_fft_tables_bank)
         return 1;
-    // decimation 8: three images back to back -- the bank's own and the all-slots form's for the even and for the odd slots (round 4)
-    const size_t images = ctx->D == 8 ? 3 : 1;
+    // decimation 8: two images back to back -- the bank's own (per-channel forms, and the all-slots form's even slots) and the
+    // all-slots form's for the odd slots (round 4)
+    const size_t images = ctx->D == 8 ? 2 : 1;
     float *tab = (float *)malloc(sizeof(float) * if_fir::FFT_TABLE_FLOATS * images);
     if (!tab)
     {
@@ -231,9 +232,9 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
     const int bank = ctx->D == 8 ? 8 : 16; // (if_fir_channelizer_process_device: decimation 8 or 16 here)
     if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)bank,
                              ctx->in_i16 ? 0x1p-15 : 1.0, tab, bank);
-    for (size_t par = 0; par + 1 < images; par++)
+    if (images == 2)
         if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)bank,
-                                 ctx->in_i16 ? 0x1p-15 : 1.0, tab + if_fir::FFT_TABLE_FLOATS * (par + 1), bank, 0, 1 + (int)par);
+                                 ctx->in_i16 ? 0x1p-15 : 1.0, tab + if_fir::FFT_TABLE_FLOATS, bank, 0, 1);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fft_tables_bank, sizeof(float) * if_fir::FFT_TABLE_FLOATS * images);
@@ -681,7 +682,7 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
         a.chan = chan;
         if (ctx->D >= 8)
             a.fft_tables = ctx->d_fft_tables_bank;
-        if (ctx->D == 8) // (the all-slots form's two images)
+        if (ctx->D == 8) // (the all-slots form's image for the odd slots)
             a.fft_tables_b = static_cast<const float *>(ctx->d_fft_tables_bank) + if_fir::FFT_TABLE_FLOATS;
     }
     a.queue_base = &ctx->queue_base;
@@ -774,7 +775,7 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
             chan.bin[c] = (uint32_t)(llround(pdFreq[c] * 4096.0) & 4095);
             chan.pword[c] = (uint32_t)(int64_t)llround(pdFreq[c] * 4294967296.0);
             chan.out[c] = (float2 *)ppDevOut[c];
-            for (int m0 = 1; m0 < 4; m0++) // decimation 4: W4096^(m0 bin), the wave-uniform factor beside the gathered table entry
+            for (int m0 = 1; m0 < 16; m0++) // W4096^(m0 bin), the wave-uniform factor beside the gathered table entry (decimation 4: m0 < 4, 8: < 8)
             {
                 const double a = -2.0 * M_PI * (double)((m0 * chan.bin[c]) & 4095u) / 4096.0;
                 chan.tw[c][2 * (m0 - 1) + 0] = (float)cos(a);
@@ -809,7 +810,7 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
         chan.pword[c] = (pulSlots[c] << 28) + pCtx->nco_word;
         for (int m0 = 1; m0 < 8; m0++) // decimation 4 uses the first three
         {
-            const double a = -2.0 * M_PI * (double)((m0 * pulSlots[c]) & 15u) / 16.0; // W16^(m0 slot)
+            const double a = -2.0 * M_PI * (double)((m0 * pulSlots[c]) & 15u) / 16.0; // W16^(m0 slot) = W4096^(m0 bin)
             chan.tw[c][2 * (m0 - 1) + 0] = (float)cos(a);
             chan.tw[c][2 * (m0 - 1) + 1] = (float)sin(a);
         }
