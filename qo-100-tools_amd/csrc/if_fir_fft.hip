@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <type_traits>
 
 #include <vector>
 
@@ -317,6 +318,14 @@ constexpr int LDS_TT = LDS_TW1 + 8192;
 #ifndef IF_FIR_FFT_TAN
 #define IF_FIR_FFT_TAN 1 // 0: the decimate-by-4 kernels in round 3's form (A/B builds)
 #endif
+// Kernel argument of the tails: the filter-bank forms (CHAN >= 4) take the whole ChanArgs (2.4 KB by value), the single-channel
+// kernels only the thinning factor -- the headline path's launches then copy 150 bytes of kernel arguments instead of 2.5 KB
+struct ChanNone
+{
+    uint32_t sub;
+};
+template <int CHAN>
+using chan_arg_t = typename std::conditional<(CHAN >= 4), ChanArgs, ChanNone>::type;
 constexpr int LDS_Q = LDS_XB + FFT_WAVES * XBUF; // workgroup block queue: slot counter (16 B) + ring of group entries
 constexpr int LDS_QPTR = LDS_Q + 16 + Q_RING * 8; // 16-slot bank: the 16 output pointers (kept out of the SGPRs)
 constexpr int LDS_QNCO = LDS_QPTR + 16 * 8; // bank tails with an NCO: the block's rotation phasor, one 8-byte word per wave
@@ -1128,7 +1137,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
                                                         int HL, int64_t N, int32_t n0, int64_t M, int64_t nblocks,
                                                         int64_t nblocks_main, unsigned int *queue, unsigned long long *dbg, int32_t diag,
-                                                        uint32_t nco_phi0, uint32_t nco_delta, ChanArgs chan,
+                                                        uint32_t nco_phi0, uint32_t nco_delta, chan_arg_t<CHAN> chan,
                                                         uint32_t qsel, void *__restrict__ hist_out,
                                                         int32_t decn, int32_t decn_n0, int64_t decn_m, int32_t in_shift)
 {
@@ -2600,6 +2609,11 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
         *a.queue_base = qsel ^ 1u;
         *a.queue_valid = true;
     }
+    chan_arg_t<CHAN> cak;
+    if constexpr (CHAN >= 4)
+        cak = ca;
+    else
+        cak.sub = ca.sub;
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), FFT_LDS_BYTES, a.stream,
                        reinterpret_cast<const f2v *>(a.in), reinterpret_cast<f2v *>(a.out),
                        reinterpret_cast<const f2v *>(a.fft_tables), reinterpret_cast<const f2v *>(a.hist_full), a.hist_len, a.N,
@@ -2607,7 +2621,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
                        (unsigned long long *)a.dbg, (int32_t)a.diag,
                        DECN ? 0u - a.nco_word * a.nco_abs0 : nco_phi0(a),
                        DECN ? 0u - a.nco_word : 0u - a.nco_word * (uint32_t)F,
-                       ca, qsel, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M,
+                       cak, qsel, a.hist_out, (int32_t)a.D, (int32_t)a.n0, a.M,
                        (int32_t)a.in_shift);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess && a.queue_valid)
