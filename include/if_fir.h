@@ -147,12 +147,12 @@ uint8_t if_fir_dev_download(if_fir_ctx_t *pCtx, void *pHost, const void *pDev, u
 uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOutBytes);
 
 /* ---- uniform filter bank (BUILD-DEFINED) -----------------------------------------------------------
- * Channel c = mix-down by pulSlots[c]/16 cycles/sample, the context's real prototype taps, decimation by the context's
- * decimation: the result of ulChannels contexts with if_fir_set_nco(slot/16.0), computed in ONE pass over the input.
+ * Channel c = mix-down by pulSlots[c]/16 cycles/sample, the context's prototype taps (real or complex), decimation by the
+ * context's decimation: the result of ulChannels contexts with if_fir_set_nco(slot/16.0), computed in ONE pass over the input.
  * The context must have <= 3073 taps, float32 or int16 input, run on the overlap-save backend and have decimation 4 (fs/16
- * channels 4x oversampled; real taps, no NCO), 8 (2x oversampled) or 16 (the channel rate: all 16 slots come out of one
+ * channels 4x oversampled; no NCO), 8 (2x oversampled) or 16 (the channel rate: all 16 slots come out of one
  * forward transform; the wanted ones are stored).  At decimation 8 and 16 the context may carry an NCO: it shifts the WHOLE
- * slot grid (channel c is centred at pulSlots[c]/16 + f_nco: a common fine offset), and complex prototype taps are accepted.
+ * slot grid (channel c is centred at pulSlots[c]/16 + f_nco: a common fine offset).
  * The context's streaming state (history, decimation phase, sample index) is shared
  * by all channels.  ulChannels 1..16, slots 0..15: any subset, repeats allowed (decimation 16: each slot at most once);
  * ppDevOut[c]: 16-byte aligned device buffers of if_fir_out_count() samples each.  Asynchronous on the context's stream
@@ -163,7 +163,7 @@ uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_t ulChannel
                                           const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples,
                                           uint64_t *pullOutSamples);
 /* Channels at ARBITRARY centre frequencies from one pass over the input (round 4; decimation 4, 8 or 16, context without NCO, real
- * or -- decimation 8 and 16 -- complex prototype taps, float32 or int16 input).  Channel c = the prototype centred at pdCentre[c] cycles/sample
+ * or complex prototype taps, float32 or int16 input).  Channel c = the prototype centred at pdCentre[c] cycles/sample
  * (|pdCentre[c]| <= 0.5), mixed down and decimated by the context's decimation:
  *     y_c[m] = exp(-j 2 pi f_c a) * sum_k h[k] exp(+j 2 pi g_c k) x[a - k],   a = absolute index of the output's input sample,
  * with g_c = the multiple of 1/4096 nearest to f_c (the overlap-save kernel moves the prototype's response by whole bins of its

@@ -2731,7 +2731,7 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
     {
         // the filter bank (decimation 4, 8, 16)
         if ((a.D != 4 && a.D != 8 && a.D != 16) || a.chan->count < 1 || a.chan->count > CHAN_MAX ||
-            (a.D == 4 && (a.nco_word || a.ctaps)))
+            (a.D == 4 && a.nco_word))
             return hipErrorInvalidConfiguration;
         const int ckey = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
         if (a.D == 8) // per channel (pairs share a small inverse)

@@ -744,10 +744,10 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
                       "carries its own centre frequency)");
         return 0;
     }
-    if ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || (pCtx->D == 4 && (pCtx->ctaps || pCtx->nco_word)) ||
+    if ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || (pCtx->D == 4 && pCtx->nco_word) ||
         !if_fir::fft_supported(pCtx->T, pCtx->D) || if_fir::fft_two_partitions(pCtx->T))
     {
-        set_err(pCtx, "if_fir_channelizer_process_device: needs <= 3073 taps and decimation 4 (real taps, no NCO), 8 or 16");
+        set_err(pCtx, "if_fir_channelizer_process_device: needs <= 3073 taps and decimation 4 (no NCO), 8 or 16");
         return 0;
     }
     if (pCtx->backend != IF_FIR_BACKEND_HIP_FFT)

@@ -1069,7 +1069,7 @@ def test_random_configurations_against_the_oracle(fir, oracle):
 
 def test_random_filter_bank_configurations_against_the_oracle(fir, oracle, torch_cuda):
     """Sweep of random filter-bank calls: decimation 4 / 8 / 16, random prototypes, random slot subsets (decimation 8:
-    repeats too -- the routing between the all-slots launches and the per-channel form follows the subset), channels at random
+    repeats too -- the routing between the all-slots launches and the per-channel form follows the subset), real and complex prototypes, channels at random
     centres on the fs/4096 grid (decimation 4 / 8 / 16), a common fine offset (the context's NCO, decimation 8 / 16), float32 / int16, random
     piece cuts.  Every channel within SPEC tolerance of the float64 NCO oracle; nothing written past a channel's outputs."""
     torch = torch_cuda
@@ -1080,7 +1080,8 @@ def test_random_filter_bank_configurations_against_the_oracle(fir, oracle, torch
         d = 4 if kind.endswith("4") else 16 if kind.endswith("16") else 8
         t = int(rng.choice([1, 2, 17, 63, 64, 65, 127, 255, 256, 257, 511, 777, 1023, 1025, 2047, 3073]))
         n = int(rng.integers(1, 40_000))
-        taps = (rng.standard_normal(t) / np.sqrt(t)).astype(np.float32)
+        ctaps = rng.random() < 0.3      # complex prototype taps (interleaved re, im)
+        taps = (rng.standard_normal(2 * t if ctaps else t) / np.sqrt(t)).astype(np.float32)
         i16 = rng.random() < 0.3
         x = rng.standard_normal(2 * n).astype(np.float32)
         if i16:
@@ -1102,7 +1103,7 @@ def test_random_filter_bank_configurations_against_the_oracle(fir, oracle, torch
         centres = [int(v) / 4096.0 for v in rng.integers(-2048, 2048, size=nch)]
         cuts = sorted(set([0, n] + [int(c) & (~3 if i16 else ~0) for c in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))]))
         xd = torch.from_numpy(xi if i16 else x).cuda()
-        with fir.IfFir(taps, d, n) as f:
+        with fir.IfFir(taps, d, n, complex_taps=ctaps) as f:
             if i16:
                 f.set_input_format(fir.INPUT_I16)
             if nco:
@@ -1126,12 +1127,12 @@ def test_random_filter_bank_configurations_against_the_oracle(fir, oracle, torch
                     parts[c].append(o[:2 * m_exp])
         for c in range(nch):
             pw = oracle.nco_phase_word(centres[c]) if freq else ((slots[c] << 28) + word) & 0xFFFFFFFF
-            ref = oracle.fir_nco_f64(taps, x, d, pw)
+            ref = oracle.fir_nco_f64(taps, x, d, pw, complex_taps=ctaps)
             got = np.concatenate(parts[c]) if parts[c] else np.zeros(0, np.float32)
             assert got.shape == ref.shape
             if ref.size and np.any(ref):
                 l2, mx = oracle.err_metrics(got, ref)
-                assert l2 <= TOL and mx <= TOL, (case, d, t, n, i16, nco, freq, slots, centres[c], cuts, l2, mx)
+                assert l2 <= TOL and mx <= TOL, (case, kind, d, t, n, i16, ctaps, nco, slots, centres[c], cuts, l2, mx)
 
 
 def test_contexts_on_concurrent_threads(fir, oracle):
