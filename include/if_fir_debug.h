@@ -45,6 +45,13 @@ uint32_t if_fir_debug_stamps(if_fir_ctx_t *pCtx, uint64_t *pullOut, uint32_t ulW
 #define IF_FIR_DEBUG_TABLE_FLOATS 21632u
 uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
                                  uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats);
+/* host-only: a filter bank's table image (ulBank 8 or 16; bank 8: ulParity 0 = the per-channel forms' image, also the all-slots
+ * form's for the even slots, 1 = the all-slots form's for the odd slots), IF_FIR_DEBUG_TABLE_FLOATS floats */
+uint32_t if_fir_debug_fft_tables_bank(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulBank, uint32_t ulParity,
+                                      float *pfOut, uint32_t ulOutFloats);
+/* host-only: routing of a decimation-8 filter-bank call on the slot grid: pulOut[0], pulOut[1] = slot masks of the all-slots
+ * launches (even / odd slots; 0 = none), pulOut[2] = bit c set: channel c goes through the per-channel form */
+uint8_t if_fir_debug_bank_plan(const uint32_t *pulSlots, uint32_t ulChannels, uint32_t *pulOut);
 /* host-only: the table image of the odd-decimation kernel (decimation 3, 9, 15, ...: 2 * (3 * 1024 + 2176) = 10496 floats) */
 #define IF_FIR_DEBUG_ODD_TABLE_FLOATS 10496u
 uint32_t if_fir_debug_fft_tables_odd(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,

@@ -2634,6 +2634,30 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
 // D = 1 and D = 4 have their own kernels; any other decimation runs the full-rate kernel with a selecting store.
 // Taps: the first T-1 outputs of a 4096-point block are discarded, in whole 64-sample rows (4, 8, 16, 32 or 48 of the
 // 64): up to 257 taps cost 6 % of the block, 513 taps 12.5 %, 1025 taps 25 %, 2049 taps half, 3073 taps three quarters.
+// Routing of a decimation-8 filter-bank call whose channels sit on the slot grid (launch_fft_rows; one definition for the launcher and
+// the CPU test): a slot parity with at least four channels, none of the call's slots listed twice, is served by ONE all-slots launch
+// (pmask[parity] = its slots, else 0); `rest` = bit c set for every channel c left to the per-channel form.
+void fft_bank8_plan(const uint32_t *slots, uint32_t count, bool all_slots_available, uint32_t pmask[2], uint32_t *rest)
+{
+    uint32_t seen = 0, m[2] = {0, 0};
+    int npar[2] = {0, 0};
+    bool dup = false;
+    for (uint32_t c = 0; c < count; c++)
+    {
+        const uint32_t sl = slots[c] & 15u;
+        dup = dup || ((seen >> sl) & 1u);
+        seen |= 1u << sl;
+        m[sl & 1u] |= 1u << sl;
+        npar[sl & 1u]++;
+    }
+    *rest = 0;
+    for (int par = 0; par < 2; par++)
+        pmask[par] = (all_slots_available && !dup && npar[par] >= 4) ? m[par] : 0u;
+    for (uint32_t c = 0; c < count; c++)
+        if (!((pmask[slots[c] & 1u] >> (slots[c] & 15u)) & 1u))
+            *rest |= 1u << c;
+}
+
 bool fft_supported(int T, int D)
 {
     return D >= 1 && D <= 64 && T >= 1 && T <= 4096;
@@ -2749,33 +2773,23 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             // other channels keep the per-channel form.  Up to three launches per call on the context's stream; only the first
             // one writes the next call's history.  (Even slots: the bank's own table image; odd slots: fft_tables_b.)
             const ChanArgs &cin = *a.chan;
-            int npar[2] = {0, 0};
-            uint32_t seen = 0;
-            bool dup = false;
-            for (uint32_t c = 0; c < cin.count; c++)
-            {
-                const uint32_t sl = cin.slot[c] & 15u;
-                dup = dup || ((seen >> sl) & 1u);
-                seen |= 1u << sl;
-                npar[sl & 1u]++;
-            }
-            const bool slots_form = !dup && a.fft_tables_b && !(a.diag & 4096); // (diag 4096, development: per-channel form only)
+            uint32_t pmask[2], rest = 0;
+            // (diag 4096, development: per-channel form only)
+            fft_bank8_plan(cin.slot, cin.count, a.fft_tables_b != nullptr && !(a.diag & 4096), pmask, &rest);
             bool first = true;
             for (uint32_t par = 0; par < 2; par++)
             {
-                if (!slots_form || npar[par] < 4)
+                if (!pmask[par])
                     continue;
                 ChanArgs cs{};
-                cs.count = (uint32_t)npar[par];
+                cs.count = (uint32_t)__builtin_popcount(pmask[par]);
                 cs.sub = par;
                 cs.rot_e = cin.abs0n0 & 15u;
                 cs.abs0n0 = cin.abs0n0;
+                cs.mask16 = pmask[par];
                 for (uint32_t c = 0; c < cin.count; c++)
-                    if ((cin.slot[c] & 1u) == par)
-                    {
+                    if ((pmask[par] >> (cin.slot[c] & 15u)) & 1u)
                         cs.out[cin.slot[c] & 15u] = cin.out[c];
-                        cs.mask16 |= 1u << (cin.slot[c] & 15u);
-                    }
                 LaunchArgs p = a;
                 p.chan = &cs;
                 p.fft_tables = par ? a.fft_tables_b : a.fft_tables; // (even slots: the bank's own image; odd slots: the image behind it)
@@ -2789,7 +2803,7 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             ChanArgs cl{};
             for (uint32_t c = 0; c < cin.count; c++)
             {
-                if (slots_form && npar[cin.slot[c] & 1u] >= 4)
+                if (!((rest >> c) & 1u))
                     continue;
                 const uint32_t k = cl.count++;
                 cl.slot[k] = cin.slot[c];
@@ -2879,7 +2893,7 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
 #ifdef IF_FIR_FFT_HAZARD_PROBE // (tests/test_host.py: one instantiation, the decimate-by-2 tail with its 16-byte stores)
 template __global__ void fir_fft_kernel<IF_FIR_FFT_ROWS, true, false, false, 2, false, false>(
     const f2v *, f2v *, const f2v *, const f2v *, int, int64_t, int32_t, int64_t, int64_t, int64_t, unsigned int *,
-    unsigned long long *, int32_t, uint32_t, uint32_t, ChanArgs, uint32_t, void *, int32_t, int32_t, int64_t, int32_t);
+    unsigned long long *, int32_t, uint32_t, uint32_t, chan_arg_t<2>, uint32_t, void *, int32_t, int32_t, int64_t, int32_t);
 #else
 template hipError_t launch_fft_rows<IF_FIR_FFT_ROWS>(const LaunchArgs &a);
 #endif

@@ -990,6 +990,25 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
 }
 
+// Host-only: the filter bank's table images (bank = 8: ulParity 0 the per-channel forms' and the all-slots form's even slots, 1 the
+// all-slots form's odd slots; bank = 16: the 16-slot image) and the routing of a decimation-8 call
+IF_FIR_API uint32_t if_fir_debug_fft_tables_bank(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulBank,
+                                                 uint32_t ulParity, float *pfOut, uint32_t ulOutFloats)
+{
+    if (!pfTaps || !pfOut || ulOutFloats < (uint32_t)if_fir::FFT_TABLE_FLOATS || (ulBank != 8 && ulBank != 16) ||
+        !if_fir::fft_supported((int)ulTaps, (int)ulBank) || if_fir::fft_two_partitions((int)ulTaps))
+        return 0;
+    if_fir::fft_build_tables(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, (int)ulBank, 0u, 1.0, pfOut, (int)ulBank, 0, ulParity ? 1 : 0);
+    return (uint32_t)if_fir::FFT_TABLE_FLOATS;
+}
+IF_FIR_API uint8_t if_fir_debug_bank_plan(const uint32_t *pulSlots, uint32_t ulChannels, uint32_t *pulOut)
+{
+    if (!pulSlots || !pulOut || ulChannels < 1 || ulChannels > (uint32_t)if_fir::CHAN_MAX)
+        return 0;
+    if_fir::fft_bank8_plan(pulSlots, ulChannels, true, pulOut, pulOut + 2);
+    return 1;
+}
+
 // Host-only: the table image of the odd-decimation kernel (fir_odd_kernel, F = 3) for a set of taps
 IF_FIR_API uint32_t if_fir_debug_fft_tables_odd(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulDecimation,
                                                 uint32_t ulNcoDelta, float *pfOut, uint32_t ulOutFloats)

@@ -31,7 +31,8 @@ EXPORTS = [
     "if_fir_mc_set_chunk_samples", "if_fir_mc_get_chunk_samples",
 ]
 # every symbol include/if_fir_debug.h declares: exported by libif_fir_dev.so only
-DEV_EXPORTS = ["if_fir_time_device", "if_fir_debug_stamps", "if_fir_debug_fft_tables", "if_fir_debug_fft_tables_odd", "if_fir_debug_fft_schedule",
+DEV_EXPORTS = ["if_fir_time_device", "if_fir_debug_stamps", "if_fir_debug_fft_tables", "if_fir_debug_fft_tables_odd", "if_fir_debug_fft_tables_bank",
+               "if_fir_debug_bank_plan", "if_fir_debug_fft_schedule",
                "if_fir_mc_debug_plan", "if_fir_debug_queue_faults"]
 MC_ID_BYTES = 128
 
@@ -407,6 +408,33 @@ def debug_fft_tables(taps, decimation, complex_taps=False, nco_delta=0):
     c = out.view(np.complex64)
     return {"tw1": c[0:4096], "hp": c[4096:8192], "tw2": c[8192:8448], "twd": c[8448:9472], "twe": c[9472:10496],
             "ncob": c[10496:10560], "twf": c[10560:10816]}
+
+
+def debug_fft_tables_bank(taps, bank, parity=0, complex_taps=False):
+    """if_fir_debug_fft_tables_bank(): a filter bank's table image (bank 8 or 16) as complex64 sections (host-only)."""
+    taps = np.ascontiguousarray(taps, dtype=np.float32)
+    t = taps.size // 2 if complex_taps else taps.size
+    out = np.zeros(FFT_TABLE_FLOATS, dtype=np.float32)
+    L = dev_lib()
+    L.if_fir_debug_fft_tables_bank.restype = ctypes.c_uint32
+    n = L.if_fir_debug_fft_tables_bank(_f32p(taps), ctypes.c_uint32(t), ctypes.c_uint32(1 if complex_taps else 0), ctypes.c_uint32(int(bank)),
+                                       ctypes.c_uint32(int(parity)), _f32p(out), ctypes.c_uint32(out.size))
+    if n != FFT_TABLE_FLOATS:
+        raise IfFirError("if_fir_debug_fft_tables_bank: (taps=%d, bank=%d) is not served" % (t, bank))
+    c = out.view(np.complex64)
+    return {"tw1": c[0:4096], "hp": c[4096:8192], "tw2": c[8192:8448], "twd": c[8448:9472], "twe": c[9472:10496], "ncob": c[10496:10560]}
+
+
+def debug_bank8_plan(slots):
+    """if_fir_debug_bank_plan(): (mask of the even slots' all-slots launch, mask of the odd slots', channels left per channel)."""
+    k = len(slots)
+    arr = (ctypes.c_uint32 * k)(*[int(v) for v in slots])
+    out = (ctypes.c_uint32 * 3)()
+    L = dev_lib()
+    L.if_fir_debug_bank_plan.restype = ctypes.c_uint8
+    if not L.if_fir_debug_bank_plan(arr, ctypes.c_uint32(k), out):
+        raise IfFirError("if_fir_debug_bank_plan: 1..16 channels")
+    return int(out[0]), int(out[1]), [c for c in range(k) if (out[2] >> c) & 1]
 
 
 def debug_fft_tables_odd(taps, decimation, complex_taps=False, nco_delta=0):

@@ -541,3 +541,54 @@ def test_keep_every_index_arithmetic_of_the_decimating_tail():
                     q2 = t // sub
                     q, rem = bq * lout + q2, t - q2 * sub
                 assert (q, rem) == divmod(blk * lout, sub), (sub, lout, blk)
+
+
+def test_filter_bank_decimation_8_routing(fir):
+    """launch_fft_rows' routing of a decimation-8 bank call on the slot grid (fft_bank8_plan, host-only): a slot parity with at least
+    four channels, no slot of the call listed twice, goes through ONE all-slots launch; everything else per channel."""
+    even, odd = 0x5555, 0xAAAA
+    assert fir.debug_bank8_plan(list(range(16))) == (even, odd, [])
+    assert fir.debug_bank8_plan([5, 0, 15, 8, 3, 10, 3]) == (0, 0, list(range(7)))          # a slot twice: per channel
+    assert fir.debug_bank8_plan([1, 5, 9, 13, 2]) == (0, (1 << 1) | (1 << 5) | (1 << 9) | (1 << 13), [4])
+    assert fir.debug_bank8_plan([7]) == (0, 0, [0])
+    assert fir.debug_bank8_plan([0, 2, 4]) == (0, 0, [0, 1, 2])                              # fewer than four of a parity
+    assert fir.debug_bank8_plan([0, 2, 4, 14, 1, 3, 5]) == (0x4015, 0, [4, 5, 6])
+    assert fir.debug_bank8_plan([3, 1, 15, 13, 11, 9, 7, 5, 0, 4]) == (0, odd, [8, 9])
+    rng = np.random.default_rng(8)
+    for _ in range(200):
+        k = int(rng.integers(1, 17))
+        slots = [int(v) for v in (rng.permutation(16)[:k] if rng.random() < 0.6 else rng.integers(0, 16, size=k))]
+        me, mo, rest = fir.debug_bank8_plan(slots)
+        assert me & odd == 0 and mo & even == 0
+        served = [c for c in range(k) if ((me | mo) >> slots[c]) & 1]
+        assert sorted(served + rest) == list(range(k))                                      # every channel exactly once
+        dup = len(set(slots)) != k
+        for par, m in ((0, me), (1, mo)):
+            want = [s for s in slots if s % 2 == par]
+            assert m == (sum(1 << s for s in set(want)) if (not dup and len(want) >= 4) else 0), (slots, par, m)
+
+
+def test_filter_bank_table_images(fir):
+    """The decimation-8 bank's two table images (fft_build_tables, host-only) against their definition in float64:
+    G_q[a] = W16^(a q) sum_j H(k_low + 256 (q + 2 j)) W8^(a j), times b^a (b = W4096^k_low: the factor input a of the last forward
+    pass still carries); the all-slots form's image for the ODD slots = the same times W16^a with the halves exchanged.  And the
+    16-slot image: G0[n2] = sum_k2 H(k_low + 256 k2) W16^(n2 k2), times b^n2."""
+    rng = np.random.default_rng(12)
+    h = rng.standard_normal(255).astype(np.float32)
+    H = np.fft.fft(h.astype(np.float64), 4096) / 4096.0
+    lane = np.arange(64)
+    W = lambda n, e: np.exp(-2j * np.pi * (np.asarray(e) % n) / n)   # noqa: E731
+    ev = fir.debug_fft_tables_bank(h, 8, 0)["hp"].astype(np.complex128)
+    od = fir.debug_fft_tables_bank(h, 8, 1)["hp"].astype(np.complex128)
+    g16 = fir.debug_fft_tables_bank(h, 16)["hp"].astype(np.complex128)
+    scale = np.abs(H).max() * 8
+    for i in range(4):
+        klow = (4 * (lane // 16) + i) + 16 * (lane % 16)
+        for q in range(2):
+            for a in range(8):
+                g = W(16, a * q) * sum(H[klow + 256 * (q + 2 * j)] * W(8, a * j) for j in range(8)) * W(4096, a * klow)
+                assert np.max(np.abs(ev[(i * 16 + 8 * q + a) * 64 + lane] - g)) <= 2e-7 * scale, (i, q, a)
+                assert np.max(np.abs(od[(i * 16 + 8 * (1 - q) + a) * 64 + lane] - g * W(16, a))) <= 2e-7 * scale, (i, q, a)
+        for n2 in range(16):
+            g = sum(H[klow + 256 * k2] * W(16, n2 * k2) for k2 in range(16)) * W(4096, n2 * klow)
+            assert np.max(np.abs(g16[(i * 16 + n2) * 64 + lane] - g)) <= 2e-7 * scale * 2, (i, n2)
