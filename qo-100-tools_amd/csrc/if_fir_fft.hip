@@ -1132,6 +1132,14 @@ hipError_t launch_fft_odd(const LaunchArgs &a)
 #endif // IF_FIR_FFT_ODD
 
 #ifdef IF_FIR_FFT_ROWS // ================= kernel + launcher: the per-overlap-length compilation units =================
+// The tail of a block after the forward transform, by CHAN (DEC4 = any decimating tail):
+//    0  full rate (DEC4 = false; DECN: selecting store), or the decimate-by-4 tail       1  decimate-by-4 tail keeping every sub-th output
+//    2  decimate-by-2 tail                                                                3  the same keeping every sub-th output
+//    4  filter bank at decimation 4, channels on the fs/16 slot grid (per channel)        5  the same, every channel at its own centre bin
+//    8  filter bank at decimation 8 per channel: slot grid (NCO = false) / any centre bin or a common offset (NCO = true)
+//    9  filter bank at decimation 8, all slots of one parity from two 8-point transforms per group
+//   16  filter bank at decimation 16, all 16 slots from one 16-point transform per group (NCO: a common offset)
+//   17  filter bank at decimation 16 per channel, every channel at its own centre bin
 template <int OVL_ROWS, bool DEC4, bool I16, bool NCO, int CHAN, bool DECN, bool ACC>
 __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__ in_, f2v *__restrict__ out,
                                                         const f2v *__restrict__ tables, const f2v *__restrict__ hist,
