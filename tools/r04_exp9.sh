@@ -2,6 +2,8 @@
 # r04_exp9.sh <tag> — round 4, batch 9 on ONE box (development tool): the odd-decimation kernel without its own load transposition (the
 # columns are rotated in registers and delivered into the first forward transposition) against the form with it
 # (libif_fir_ab_oddold.so): its GPU tests, then in-process A/B; the filter bank's general form timed in full.
+# (needs qo-100-tools_amd/libif_fir_ab_oddold.so: `tools/build_ab.sh oddold` on a tree at commit cd7127b, the last one with the kernel's own
+# transposition phase; the A/B libraries are not kept in the repository)
 cd "$(dirname "$0")/.."
 O=gpurun_out/$1
 mkdir -p $O
