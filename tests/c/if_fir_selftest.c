@@ -186,6 +186,25 @@ int main(void)
                   max_rel_err(pfY, pdRef, 2 * ullOut));
             CHECK(if_fir_dev_free(pFir, apDevOut[c]), "free");
         }
+        /* the same context: three channels at their own centres (multiples of fs/4096: exactly what three contexts with
+         * if_fir_set_nco compute), from one pass */
+        {
+            const double adCentre[3] = {300.0 / 4096.0, -1000.0 / 4096.0, 0.25};
+            CHECK(if_fir_reset(pFir), "reset");
+            for(uint32_t c = 0; c < 3; c++)
+                CHECK(if_fir_dev_alloc(pFir, &apDevOut[c], 8 * (ullOut16 + 2)), "device output");
+            CHECK(if_fir_channelizer_process_device_freq(pFir, 3, adCentre, pDevIn, apDevOut, SAMPLES, &ullOut) && ullOut == ullOut16,
+                  "channels at their own centres: %s", if_fir_last_error(pFir));
+            CHECK(if_fir_synchronize(pFir), "synchronize");
+            for(uint32_t c = 0; c < 3; c++)
+            {
+                reference(pfTaps, TAPS, DECIM16, (uint32_t)(int64_t)llround(adCentre[c] * 4294967296.0), pfX, SAMPLES, pdRef);
+                CHECK(if_fir_dev_download(pFir, pfY, apDevOut[c], 8 * ullOut), "download");
+                CHECK(max_rel_err(pfY, pdRef, 2 * ullOut) <= 1e-6, "channel at centre %g error %g", adCentre[c],
+                      max_rel_err(pfY, pdRef, 2 * ullOut));
+                CHECK(if_fir_dev_free(pFir, apDevOut[c]), "free");
+            }
+        }
         /* and one tuned, decimated channel the ordinary way: NCO + decimate-by-16 through if_fir_process */
         CHECK(if_fir_reset(pFir) && if_fir_set_nco(pFir, 0.1371) && if_fir_get_nco(pFir, &dFreq), "NCO: %s", if_fir_last_error(pFir));
         reference(pfTaps, TAPS, DECIM16, (uint32_t)(int64_t)llround(dFreq * 4294967296.0), pfX, SAMPLES, pdRef);
