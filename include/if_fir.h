@@ -162,8 +162,8 @@ uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOu
 uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots,
                                           const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples,
                                           uint64_t *pullOutSamples);
-/* Channels at ARBITRARY centre frequencies from one pass over the input (round 4; decimation 4, 8 or 16, context without NCO, real
- * or complex prototype taps, float32 or int16 input).  Channel c = the prototype centred at pdCentre[c] cycles/sample
+/* Channels at ARBITRARY centre frequencies from one pass over the input (round 4; decimation 4, 8, 12, ..., 64 -- any multiple of 4 --,
+ * context without NCO, real or complex prototype taps, float32 or int16 input).  Channel c = the prototype centred at pdCentre[c] cycles/sample
  * (|pdCentre[c]| <= 0.5), mixed down and decimated by the context's decimation:
  *     y_c[m] = exp(-j 2 pi f_c a) * sum_k h[k] exp(+j 2 pi g_c k) x[a - k],   a = absolute index of the output's input sample,
  * with g_c = the multiple of 1/4096 nearest to f_c (the overlap-save kernel moves the prototype's response by whole bins of its

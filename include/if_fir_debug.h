@@ -49,6 +49,9 @@ uint32_t if_fir_debug_fft_tables(const float *pfTaps, uint32_t ulTaps, uint32_t 
  * form's for the even slots, 1 = the all-slots form's for the odd slots), IF_FIR_DEBUG_TABLE_FLOATS floats */
 uint32_t if_fir_debug_fft_tables_bank(const float *pfTaps, uint32_t ulTaps, uint32_t bComplexTaps, uint32_t ulBank, uint32_t ulParity,
                                       float *pfOut, uint32_t ulOutFloats);
+/* host-only: the filter bank's tail for a decimation (4, 8 or 16; bOwnCentres: channels at their own centres, every multiple of 4 up
+ * to 64 -- the tail then keeps every (decimation / tail)-th output); 0 = not served */
+uint32_t if_fir_debug_bank_tail(uint32_t ulDecimation, uint32_t bOwnCentres);
 /* host-only: routing of a decimation-8 filter-bank call on the slot grid: pulOut[0], pulOut[1] = slot masks of the all-slots
  * launches (even / odd slots; 0 = none), pulOut[2] = bit c set: channel c goes through the per-channel form */
 uint8_t if_fir_debug_bank_plan(const uint32_t *pulSlots, uint32_t ulChannels, uint32_t *pulOut);

@@ -1814,16 +1814,21 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 const float2 pa = nco_phasor(0u - pw * (chan.abs0n0 + 16u * (uint32_t)o0));
                 const cf wl = {pa.x, pa.y};
                 const f2v *rowp = rowt + cl * 16;
+                // decimation 32, 48, 64 (16 x sub): every sub-th output of this tail is a real output (KeepEvery, as behind the
+                // single-channel tails; sub = 1: all of them)
+                KeepEvery ke;
+                ke.init(blk, (unsigned)LOUT, chan.sub);
                 if (cq + cs < nch && !(diag & 2))
                 {
 #pragma unroll
                     for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
                     {
                         const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
-                        if (idx < M)
+                        const int64_t kept = ke.index((unsigned)mu1 + 16u * (unsigned)(mu0 - MU0_FIRST));
+                        if (idx < M && kept >= 0)
                         {
                             const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
-                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + kept);
                         }
                     }
                 }
@@ -2105,16 +2110,20 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 const float2 pa = nco_phasor(0u - pw * (chan.abs0n0 + 8u * (uint32_t)o0));
                 const cf wl = {pa.x, pa.y};
                 const f2v *rowp = rowt + (chl ? c1 : cp) * 16;
+                // decimation 24, 40, 56 (8 x sub): every sub-th output of this tail is a real output (KeepEvery; sub = 1: all of them)
+                KeepEvery ke;
+                ke.init(blk, (unsigned)LOUT, chan.sub);
                 if (cl < nch && !(diag & 2))
                 {
 #pragma unroll
                     for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
                     {
                         const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
-                        if (idx < M)
+                        const int64_t kept = ke.index((unsigned)(2 * (lane >> 2) + (lane & 1)) + 32u * (unsigned)(mu0 - MU0_FIRST));
+                        if (idx < M && kept >= 0)
                         {
                             const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
-                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + kept);
                         }
                     }
                 }
@@ -2277,10 +2286,20 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 const float2 pa = nco_phasor(0u - chan.pword[ch] * (chan.abs0n0 + 4u * (uint32_t)(obase + lane)));
                 const cf wl = {pa.x, pa.y};
                 const f2v *rowp = rowt + ch * 16;
-                const srd_t csrd = make_srd(chan.out[ch] + obase, (diag & 2) ? 0 : (M - obase) * 8);
+                // decimation 12, 20, 28, ... (4 x sub): every sub-th output of this tail is a real output (KeepEvery, as in the
+                // single-channel tail; sub = 1: all of them).  Descriptor over the kept outputs from this block's first one on.
+                KeepEvery ke;
+                ke.init(blk, (unsigned)LOUT, chan.sub);
+                const int64_t qb = ke.qU + (ke.rem ? 1 : 0);
+                const srd_t csrd = make_srd(chan.out[ch] + qb, (diag & 2) ? 0 : (decn_m - qb) * 8);
+                const int lim = (int)((M - obase) < 65536 ? (M - obase) : 65536); // tail outputs of the call left from this block on
 #pragma unroll
                 for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                    buf_store(csrd, voff, (mu0 - MU0_FIRST) * 512, cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST])));
+                {
+                    const int64_t kept = ke.index((unsigned)lane + 64u * (unsigned)(mu0 - MU0_FIRST));
+                    const unsigned so = (kept >= 0 && lane + 64 * (mu0 - MU0_FIRST) < lim) ? (unsigned)(kept - qb) * 8u : 0xffffffffu;
+                    buf_store(csrd, so, 0, cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST])));
+                }
             }
         }
         else if constexpr (DEC4)
@@ -2587,7 +2606,8 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     // (decimation 4 sub behind the decimate-by-4 tail, CHAN == 1: the tail runs at the fs/4 rate and keeps every sub-th output)
     constexpr int F = (CHAN == 16 || CHAN == 17) ? 16 : (CHAN == 8 || CHAN == 9) ? 8 : (CHAN == 2 || CHAN == 3) ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
     ChanArgs ca = a.chan ? *a.chan : ChanArgs{};
-    ca.sub = CHAN == 1 ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : CHAN == 9 ? (ca.sub & 1u) /* the parity */ : 1u;
+    ca.sub = (CHAN == 1 || CHAN == 5) ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : CHAN == 9 ? (ca.sub & 1u) /* the parity */
+             : (CHAN == 8 && NCO) ? (uint32_t)(a.D / 8) : CHAN == 17 ? (uint32_t)(a.D / 16) : 1u; // (general bank forms: D = F x sub)
     const int64_t m_rate = DECN ? a.N : CHAN == 9 ? a.M : (a.M - 1) * (int64_t)ca.sub + 1; // (CHAN 9: `sub` carries the slot parity)
     const int32_t n0_rate = DECN ? 0 : a.n0;
     const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
@@ -2664,6 +2684,17 @@ void fft_bank8_plan(const uint32_t *slots, uint32_t count, bool all_slots_availa
     for (uint32_t c = 0; c < count; c++)
         if (!((pmask[slots[c] & 1u] >> (slots[c] & 15u)) & 1u))
             *rest |= 1u << c;
+}
+
+// The filter bank's tail for a decimation: 4, 8, 16 themselves; channels at their own centres (`general`) also every other multiple
+// of 4 up to 64 -- the largest of 16, 8, 4 that divides it, the tail then keeps every (D / F)-th output.  0: not served.
+int fft_bank_tail(int D, bool general)
+{
+    if (D == 4 || D == 8 || D == 16)
+        return D;
+    if (!general || D < 4 || D > 64 || (D & 3))
+        return 0;
+    return (D % 16 == 0) ? 16 : (D % 8 == 0) ? 8 : 4;
 }
 
 bool fft_supported(int T, int D)
@@ -2761,12 +2792,13 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
     {
     if (a.chan)
     {
-        // the filter bank (decimation 4, 8, 16)
-        if ((a.D != 4 && a.D != 8 && a.D != 16) || a.chan->count < 1 || a.chan->count > CHAN_MAX ||
-            (a.D == 4 && a.nco_word))
+        // the filter bank: decimation 4, 8, 16; channels at their own centres (chan->general) also at every other multiple of 4 up to 64,
+        // behind the tail of the largest of 16, 8, 4 that divides the decimation, keeping every sub-th output
+        const int Fb = fft_bank_tail(a.D, a.chan->general != 0);
+        if (!Fb || a.chan->count < 1 || a.chan->count > CHAN_MAX || (Fb == 4 && a.nco_word))
             return hipErrorInvalidConfiguration;
         const int ckey = (a.in_i16 ? 2 : 0) | (a.nco_word ? 1 : 0);
-        if (a.D == 8) // per channel (pairs share a small inverse)
+        if (Fb == 8) // per channel (pairs share a small inverse)
         {
             // slot form (chan->tw[] = W16^(a slot), a = 1..7) when every channel sits on the fs/16 grid and the context has no NCO;
             // the general form (chan->bin[] / pword[]: centre bin and mix-down word of a channel) otherwise
@@ -2832,9 +2864,9 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
                 p.hist_out = nullptr;
             return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 8>(p) : launch_fft_t<ROWS, true, false, false, 8>(p);
         }
-        if (a.D == 16 && a.chan->general) // every channel at its own centre (per channel; arrays indexed by channel)
+        if (Fb == 16 && a.chan->general) // every channel at its own centre (per channel; arrays indexed by channel)
             return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 17>(a) : launch_fft_t<ROWS, true, false, false, 17>(a);
-        if (a.D == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
+        if (Fb == 16) // all 16 slots from one forward transform; chan->out[] / rot0[] are indexed by SLOT
             switch (ckey)
             {
             case 0: return launch_fft_t<ROWS, true, false, false, 16>(a);

@@ -135,6 +135,7 @@ void fft_schedule(int64_t nblocks, int64_t wgs_max, FftSchedule &s); // host-onl
 hipError_t launch_fft(const LaunchArgs &a);
 // bank = 8 / 16: the merged table of the filter bank at decimation 8 / 16 in place of H; full_rate (D != 4, no bank): the image of
 // the full-rate pipeline (D = 1, the selecting store) with its twiddles in (cos, tan) form -- the decimate-by-2 tails keep the plain one
+int fft_bank_tail(int D, bool general);
 void fft_bank8_plan(const uint32_t *slots, uint32_t count, bool all_slots_available, uint32_t pmask[2], uint32_t *rest);
 void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_delta, double in_scale, float *tables,
                       int bank = 0, int full_rate = 0, int bank_parity = 0);

@@ -221,7 +221,8 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
         return 1;
     // decimation 8: two images back to back -- the bank's own (per-channel forms, and the all-slots form's even slots) and the
     // all-slots form's for the odd slots (round 4)
-    const size_t images = ctx->D == 8 ? 2 : 1;
+    const int bank = if_fir::fft_bank_tail(ctx->D, true); // 8 or 16 (decimation 8 / 16 themselves, or the tail behind 24, 32, ..., 64)
+    const size_t images = bank == 8 ? 2 : 1;
     float *tab = (float *)malloc(sizeof(float) * if_fir::FFT_TABLE_FLOATS * images);
     if (!tab)
     {
@@ -229,7 +230,6 @@ static uint8_t ensure_bank_tables(if_fir_ctx *ctx)
         return 0;
     }
     // (the NCO's effective complex taps and its per-output phase step, like the single-channel tables)
-    const int bank = ctx->D == 8 ? 8 : 16; // (if_fir_channelizer_process_device: decimation 8 or 16 here)
     if_fir::fft_build_tables(eff_taps(ctx), ctx->T, eff_ctaps(ctx), ctx->D, 0u - ctx->nco_word * (uint32_t)bank,
                              ctx->in_i16 ? 0x1p-15 : 1.0, tab, bank);
     if (images == 2)
@@ -680,9 +680,10 @@ static uint8_t run_device(if_fir_ctx *ctx, const void *in, void *out, uint64_t n
         }
         chan->abs0n0 = (uint32_t)(ctx->consumed + n0);
         a.chan = chan;
-        if (ctx->D >= 8)
+        const int fb = if_fir::fft_bank_tail(ctx->D, chan->general != 0);
+        if (fb >= 8)
             a.fft_tables = ctx->d_fft_tables_bank;
-        if (ctx->D == 8) // (the all-slots form's image for the odd slots)
+        if (fb == 8) // (the all-slots form's image for the odd slots)
             a.fft_tables_b = static_cast<const float *>(ctx->d_fft_tables_bank) + if_fir::FFT_TABLE_FLOATS;
     }
     a.queue_base = &ctx->queue_base;
@@ -724,7 +725,7 @@ IF_FIR_API uint8_t if_fir_process_device(if_fir_ctx_t *pCtx, const void *pDevIn,
 // Uniform filter bank (BUILD-DEFINED): channel c = the context's real prototype taps applied after a
 // mix-down by pulSlots[c]/16 cycles/sample, decimated by 4 -- the same result as ulChannels contexts with
 // if_fir_set_nco(slot/16), from ONE pass over the input (one forward transform per block, one small inverse per channel).
-// pdFreq != nullptr (if_fir_channelizer_process_device_freq, decimation 4, 8 or 16): channel c is centred at pdFreq[c] cycles/sample
+// pdFreq != nullptr (if_fir_channelizer_process_device_freq, decimation 4, 8, 12, ..., 64): channel c is centred at pdFreq[c] cycles/sample
 // instead of on a slot
 static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots, const double *pdFreq,
                                const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples, uint64_t *pullOutSamples)
@@ -738,13 +739,14 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
         set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot (or centre) and output arrays", if_fir::CHAN_MAX);
         return 0;
     }
-    if (pdFreq && ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || pCtx->nco_word))
+    const int fb = if_fir::fft_bank_tail((int)pCtx->D, pdFreq != nullptr); // the bank's tail: 4, 8 or 16 (0: decimation not served)
+    if (pdFreq && (!fb || pCtx->nco_word))
     {
-        set_err(pCtx, "if_fir_channelizer_process_device_freq: needs a context with decimation 4, 8 or 16 and no NCO (every channel "
-                      "carries its own centre frequency)");
+        set_err(pCtx, "if_fir_channelizer_process_device_freq: needs a context with decimation 4, 8, 12, ..., 64 (a multiple of 4) and no "
+                      "NCO (every channel carries its own centre frequency)");
         return 0;
     }
-    if ((pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16) || (pCtx->D == 4 && pCtx->nco_word) ||
+    if (!fb || (fb == 4 && pCtx->nco_word) ||
         !if_fir::fft_supported(pCtx->T, pCtx->D) || if_fir::fft_two_partitions(pCtx->T))
     {
         set_err(pCtx, "if_fir_channelizer_process_device: needs <= 3073 taps and decimation 4 (no NCO), 8 or 16");
@@ -821,7 +823,7 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
         return 0;
     }
     HIP_TRY(pCtx, hipSetDevice(pCtx->device));
-    if (!ensure_fft_tables(pCtx) || (pCtx->D != 4 && !ensure_bank_tables(pCtx)))
+    if (!ensure_fft_tables(pCtx) || (fb != 4 && !ensure_bank_tables(pCtx)))
         return 0;
     return run_device(pCtx, pDevIn, ppDevOut[0], ullSamples, pullOutSamples, true, &chan);
 }
@@ -1000,6 +1002,10 @@ IF_FIR_API uint32_t if_fir_debug_fft_tables_bank(const float *pfTaps, uint32_t u
         return 0;
     if_fir::fft_build_tables(pfTaps, (int)ulTaps, bComplexTaps ? 1 : 0, (int)ulBank, 0u, 1.0, pfOut, (int)ulBank, 0, ulParity ? 1 : 0);
     return (uint32_t)if_fir::FFT_TABLE_FLOATS;
+}
+IF_FIR_API uint32_t if_fir_debug_bank_tail(uint32_t ulDecimation, uint32_t bOwnCentres)
+{
+    return (uint32_t)if_fir::fft_bank_tail((int)ulDecimation, bOwnCentres != 0);
 }
 IF_FIR_API uint8_t if_fir_debug_bank_plan(const uint32_t *pulSlots, uint32_t ulChannels, uint32_t *pulOut)
 {

@@ -32,7 +32,7 @@ EXPORTS = [
 ]
 # every symbol include/if_fir_debug.h declares: exported by libif_fir_dev.so only
 DEV_EXPORTS = ["if_fir_time_device", "if_fir_debug_stamps", "if_fir_debug_fft_tables", "if_fir_debug_fft_tables_odd", "if_fir_debug_fft_tables_bank",
-               "if_fir_debug_bank_plan", "if_fir_debug_fft_schedule",
+               "if_fir_debug_bank_plan", "if_fir_debug_bank_tail", "if_fir_debug_fft_schedule",
                "if_fir_mc_debug_plan", "if_fir_debug_queue_faults"]
 MC_ID_BYTES = 128
 
@@ -284,7 +284,7 @@ class IfFir:
         return int(m.value)
 
     def channelizer_process_device_freq(self, centres, dev_in, dev_outs, samples):
-        """if_fir_channelizer_process_device_freq(): channel c centred at centres[c] cycles/sample (decimation 4, 8 or 16)."""
+        """if_fir_channelizer_process_device_freq(): channel c centred at centres[c] cycles/sample (decimation 4, 8, 12, ..., 64)."""
         k = len(centres)
         fc = (ctypes.c_double * k)(*[float(v) for v in centres])
         po = (ctypes.c_void_p * k)(*[ctypes.c_void_p(int(p)) for p in dev_outs])
@@ -423,6 +423,13 @@ def debug_fft_tables_bank(taps, bank, parity=0, complex_taps=False):
         raise IfFirError("if_fir_debug_fft_tables_bank: (taps=%d, bank=%d) is not served" % (t, bank))
     c = out.view(np.complex64)
     return {"tw1": c[0:4096], "hp": c[4096:8192], "tw2": c[8192:8448], "twd": c[8448:9472], "twe": c[9472:10496], "ncob": c[10496:10560]}
+
+
+def debug_bank_tail(decimation, own_centres=False):
+    """if_fir_debug_bank_tail(): the bank's tail (4, 8, 16) for a decimation, 0 if the bank does not serve it."""
+    L = dev_lib()
+    L.if_fir_debug_bank_tail.restype = ctypes.c_uint32
+    return int(L.if_fir_debug_bank_tail(ctypes.c_uint32(int(decimation)), ctypes.c_uint32(1 if own_centres else 0)))
 
 
 def debug_bank8_plan(slots):

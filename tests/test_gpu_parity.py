@@ -933,7 +933,9 @@ def test_filter_bank_with_a_common_fine_offset(fir, oracle, torch_cuda, d, i16):
 
 @pytest.mark.parametrize("t,i16,d", [(255, False, 8), (1023, False, 8), (127, True, 8), (511, False, 8),
                                      (255, False, 16), (1023, True, 16), (63, False, 16), (2047, False, 16),
-                                     (255, False, 4), (127, True, 4), (1023, False, 4), (3073, False, 4)])
+                                     (255, False, 4), (127, True, 4), (1023, False, 4), (3073, False, 4),
+                                     # every other multiple of 4: the tail of the largest of 16 / 8 / 4 dividing it, keeping every (D / F)-th output
+                                     (255, False, 32), (511, True, 64), (255, False, 12), (1023, False, 24), (255, True, 48), (127, False, 20)])
 def test_filter_bank_channels_at_arbitrary_centre_frequencies(fir, oracle, torch_cuda, t, i16, d):
     """Round 4: channels at ARBITRARY centres from one pass (decimation 8, and 16 = the channel rate, four channels per
     small inverse; and 4, one 1024-point inverse per channel): the prototype moved up by the multiple
@@ -1011,7 +1013,7 @@ def test_filter_bank_channels_at_arbitrary_centre_frequencies(fir, oracle, torch
         with pytest.raises(fir.IfFirError, match="no NCO"):
             f.channelizer_process_device_freq([0.1], xd.data_ptr(), [out.data_ptr()], 16)
     with fir.IfFir(taps, 2, n) as f:
-        with pytest.raises(fir.IfFirError, match="decimation 4, 8 or 16"):
+        with pytest.raises(fir.IfFirError, match="multiple of 4"):
             f.channelizer_process_device_freq([0.1], xd.data_ptr(), [xd.data_ptr()], 16)
 
 
@@ -1070,14 +1072,14 @@ def test_random_configurations_against_the_oracle(fir, oracle):
 def test_random_filter_bank_configurations_against_the_oracle(fir, oracle, torch_cuda):
     """Sweep of random filter-bank calls: decimation 4 / 8 / 16, random prototypes, random slot subsets (decimation 8:
     repeats too -- the routing between the all-slots launches and the per-channel form follows the subset), real and complex prototypes, channels at random
-    centres on the fs/4096 grid (decimation 4 / 8 / 16), a common fine offset (the context's NCO, decimation 8 / 16), float32 / int16, random
+    centres on the fs/4096 grid (decimation 4 / 8 / 16 and other multiples of 4), a common fine offset (the context's NCO, decimation 8 / 16), float32 / int16, random
     piece cuts.  Every channel within SPEC tolerance of the float64 NCO oracle; nothing written past a channel's outputs."""
     torch = torch_cuda
     rng = np.random.default_rng(int(os.environ.get("IF_FIR_TEST_SEED", "20261004")) + 17)   # other seeds: soak runs
-    schedule = ["slots4", "slots8", "slots16", "freq4", "freq8", "freq16", "nco8", "nco16", "allslots"]   # every form in turn, the rest random
-    for case in range(45):
-        kind = schedule[case % len(schedule)]
-        d = 4 if kind.endswith("4") else 16 if kind.endswith("16") else 8
+    schedule = [("slots", 4), ("slots", 8), ("slots", 16), ("freq", 4), ("freq", 8), ("freq", 16), ("nco", 8), ("nco", 16), ("allslots", 8),
+                ("freq", 12), ("freq", 24), ("freq", 32), ("freq", 64), ("freq", 40)]   # every form in turn, the rest random
+    for case in range(56):
+        kind, d = schedule[case % len(schedule)]
         t = int(rng.choice([1, 2, 17, 63, 64, 65, 127, 255, 256, 257, 511, 777, 1023, 1025, 2047, 3073]))
         n = int(rng.integers(1, 40_000))
         ctaps = rng.random() < 0.3      # complex prototype taps (interleaved re, im)

@@ -568,6 +568,16 @@ def test_filter_bank_decimation_8_routing(fir):
             assert m == (sum(1 << s for s in set(want)) if (not dup and len(want) >= 4) else 0), (slots, par, m)
 
 
+def test_filter_bank_tail_by_decimation(fir):
+    """fft_bank_tail (host-only): the slot API serves decimation 4, 8, 16; channels at their own centres every multiple of 4 up to 64,
+    behind the tail of the largest of 16, 8, 4 that divides the decimation."""
+    for d in range(0, 70):
+        slot = d if d in (4, 8, 16) else 0
+        own = 0 if (d < 4 or d > 64 or d % 4) else 16 if d % 16 == 0 else 8 if d % 8 == 0 else 4
+        assert fir.debug_bank_tail(d) == slot, d
+        assert fir.debug_bank_tail(d, True) == own, d
+
+
 def test_filter_bank_table_images(fir):
     """The decimation-8 bank's two table images (fft_build_tables, host-only) against their definition in float64:
     G_q[a] = W16^(a q) sum_j H(k_low + 256 (q + 2 j)) W8^(a j), times b^a (b = W4096^k_low: the factor input a of the last forward
