@@ -46,3 +46,32 @@ def test_stream_filter_program(gpu_ok):
     l2, mx = oracle.err_metrics(y, ref)
     assert l2 <= 1e-6 and mx <= 1e-6, (l2, mx)
     assert b"100003 samples in, 25001 out" in run.stderr
+
+
+@pytest.mark.gpu
+def test_channelizer_program(gpu_ok, tmp_path):
+    """qo-100-tools_amd/host/if_fir_channelize: stdin -> one file per channel (C, on the C ABI): three narrow channels at their own
+    centres out of one int16 stream, decimated by 64, fed in calls of 8192 samples; every file against the float64 NCO oracle."""
+    import numpy as np
+    import __graft_entry__ as g
+    oracle = g.load_oracle()
+    fir = g.load_pkg().if_fir
+    exe = os.path.join(ROOT, "qo-100-tools_amd", "host", "if_fir_channelize")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "if_fir_channelize"])
+    n, d = 200_003, 64
+    centres = [440 / 4096.0, -823 / 4096.0, 0.25]
+    xi = np.clip(np.round(oracle.synth_iq(n, 9) * 14000.0), -32768, 32767).astype(np.int16)
+    run = subprocess.run([exe, "-t", "255", "-d", str(d), "-w", "0.006", "-f", ",".join("%.12f" % c for c in centres),
+                          "-o", str(tmp_path / "nb_%u.cf32"), "-i", "s16", "-c", "8192"],
+                         input=xi.tobytes(), capture_output=True, timeout=300)
+    assert run.returncode == 0, run.stderr.decode()
+    taps = fir.bpf_design(255, 0.0, 0.006)
+    x = xi.astype(np.float32) * np.float32(2.0 ** -15)
+    for c, fc in enumerate(centres):
+        y = np.fromfile(str(tmp_path / ("nb_%u.cf32" % c)), dtype=np.float32)
+        ref = oracle.fir_nco_f64(taps, x, d, oracle.nco_phase_word(fc))
+        assert y.shape == ref.shape, (c, y.shape, ref.shape)
+        l2, mx = oracle.err_metrics(y, ref)
+        assert l2 <= 1e-6 and mx <= 1e-6, (c, l2, mx)
+    assert b"200003 samples in, 3126 out per channel, 3 channels" in run.stderr
