@@ -30,7 +30,7 @@ timeout -k 10 600 bash tools/same_box.sh ${TAG}_same | tail -12
 step "small calls"
 IF_FIR_DEBUG=1 timeout -k 10 200 python3 tools/small_calls.py > $O/small_calls.txt 2>&1; tail -6 $O/small_calls.txt
 step "filter bank"
-for spec in "8 28 255 4" "8 28 255 8" "16 28 255 8" "8 28 255 8 tuning=1004096" "8 28 255 4 freq" "8 28 255 8 freq" "16 28 255 8 freq" "8 28 255 16 freq" "16 28 255 16 freq" "16 28 255 16"; do
+for spec in "8 28 255 4" "8 28 255 8" "16 28 255 8" "8 28 255 8 tuning=1004096" "8 28 255 4 freq" "8 28 255 8 freq" "16 28 255 8 freq" "8 28 255 16 freq" "16 28 255 16 freq" "8 28 255 64 freq" "16 28 255 16"; do
   IF_FIR_DEBUG=1 timeout -k 10 300 python3 tools/fbank_bench.py $spec 2>&1 | tail -1 | cut -c1-1500 | tee -a $O/fbank.txt | cut -c1-300
 done
 step done
