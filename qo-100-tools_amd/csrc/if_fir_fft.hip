@@ -1136,6 +1136,7 @@ hipError_t launch_fft_odd(const LaunchArgs &a)
 //    0  full rate (DEC4 = false; DECN: selecting store), or the decimate-by-4 tail       1  decimate-by-4 tail keeping every sub-th output
 //    2  decimate-by-2 tail                                                                3  the same keeping every sub-th output
 //    4  filter bank at decimation 4, channels on the fs/16 slot grid (per channel)        5  the same, every channel at its own centre bin
+//    6  tail 5 keeping every sub-th output (decimation 12, 20, 28, ...; tails 8-general and 17 do that inside, by a wave-uniform branch)
 //    8  filter bank at decimation 8 per channel: slot grid (NCO = false) / any centre bin or a common offset (NCO = true)
 //    9  filter bank at decimation 8, all slots of one parity from two 8-point transforms per group
 //   16  filter bank at decimation 16, all 16 slots from one 16-point transform per group (NCO: a common offset)
@@ -1160,9 +1161,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // (1 = the decimate-by-4 tail keeping every sub-th output: decimation 8, 12, ..., 64; 3 = the decimate-by-2 tail doing the same:
     // decimation 6, 10, ..., 62)
     // (9, round 4 = the bank at decimation 8 in its all-slots form: the eight slots of ONE parity from two 8-point transforms per group)
-    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 5 || CHAN == 8 || CHAN == 9 || CHAN == 16 || CHAN == 17) && DEC4),
+    static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 5 || CHAN == 6 || CHAN == 8 || CHAN == 9 || CHAN == 16 || CHAN == 17) && DEC4),
                   "decimating tails: 1, 2, 3, or the bank at 4 (4: slots, 5: any centre), 8 (8: per channel, 9: all slots of a parity), 16 (16: all slots, 17: per channel)");
-    static_assert(CHAN != 5 || !NCO, "channels at their own centres: no common offset on top");
+    static_assert((CHAN != 5 && CHAN != 6) || !NCO, "channels at their own centres: no common offset on top");
     static_assert(CHAN != 9 || !NCO, "the all-slots form serves channels on the slot grid");
     static_assert(CHAN != 17 || !NCO, "channels at their own centres: no common offset on top");
     static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
@@ -1172,7 +1173,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     // diag (development only, results are wrong when set): 1 = skip the global loads, 2 = skip the global stores
     // decimate-by-4 kernels (single channel incl. the multiples of 4, and the bank at decimation 4): twiddles in (cos, tan) form
     // on the inputs of passes 2 and 3 and of the small inverse (round 4); every other tail keeps round 3's form and tables
-    constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4 || CHAN == 5 || CHAN == 8 || CHAN == 9 || CHAN == 16 || CHAN == 17); // (8, 9, 16, 17: the banks' own images)
+    constexpr bool TAN = IF_FIR_FFT_TAN && DEC4 && (CHAN == 0 || CHAN == 1 || CHAN == 4 || CHAN == 5 || CHAN == 6 || CHAN == 8 || CHAN == 9 || CHAN == 16 || CHAN == 17); // (8, 9, 16, 17: the banks' own images)
     // the full-rate pipeline the same way, forward and inverse (the inverse's twiddles already sat on the inputs of its passes)
     constexpr bool TANF = IF_FIR_FFT_TAN && !DEC4;
     constexpr int OVL = 64 * OVL_ROWS;
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             if (threadIdx.x < 16)
                 reinterpret_cast<float2 **>(smem + LDS_QPTR)[threadIdx.x] = chan.out[threadIdx.x];
         }
-        if constexpr (CHAN == 8 || CHAN == 17 || CHAN == 5)
+        if constexpr (CHAN == 8 || CHAN == 17 || CHAN == 5 || CHAN == 6)
         {
             // per channel, the phasors of output rows 0..15 of a block: row k is 32 outputs (decimation 16: 16, decimation 4: 64) = 256
             // input samples behind row 0
@@ -1816,19 +1817,38 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 const f2v *rowp = rowt + cl * 16;
                 // decimation 32, 48, 64 (16 x sub): every sub-th output of this tail is a real output (KeepEvery, as behind the
                 // single-channel tails; sub = 1: all of them)
-                KeepEvery ke;
-                ke.init(blk, (unsigned)LOUT, chan.sub);
-                if (cq + cs < nch && !(diag & 2))
+                if (chan.sub == 1u) // (wave-uniform: the plain decimation keeps its plain store loop -- the thinning costs it 5 %)
                 {
-#pragma unroll
-                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    if (cq + cs < nch && !(diag & 2))
                     {
-                        const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
-                        const int64_t kept = ke.index((unsigned)mu1 + 16u * (unsigned)(mu0 - MU0_FIRST));
-                        if (idx < M && kept >= 0)
+#pragma unroll
+                        for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
                         {
-                            const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
-                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + kept);
+                            const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
+                            if (idx < M)
+                            {
+                                const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
+                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                            }
+                        }
+                    }
+                }
+                else
+                {
+                    KeepEvery ke;
+                    ke.init(blk, (unsigned)LOUT, chan.sub);
+                    if (cq + cs < nch && !(diag & 2))
+                    {
+#pragma unroll
+                        for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                        {
+                            const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
+                            const int64_t kept = ke.index((unsigned)mu1 + 16u * (unsigned)(mu0 - MU0_FIRST));
+                            if (idx < M && kept >= 0)
+                            {
+                                const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
+                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + kept);
+                            }
                         }
                     }
                 }
@@ -2111,19 +2131,38 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 const cf wl = {pa.x, pa.y};
                 const f2v *rowp = rowt + (chl ? c1 : cp) * 16;
                 // decimation 24, 40, 56 (8 x sub): every sub-th output of this tail is a real output (KeepEvery; sub = 1: all of them)
-                KeepEvery ke;
-                ke.init(blk, (unsigned)LOUT, chan.sub);
-                if (cl < nch && !(diag & 2))
+                if (chan.sub == 1u) // (wave-uniform: decimation 8 itself keeps its plain store loop)
                 {
-#pragma unroll
-                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    if (cl < nch && !(diag & 2))
                     {
-                        const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
-                        const int64_t kept = ke.index((unsigned)(2 * (lane >> 2) + (lane & 1)) + 32u * (unsigned)(mu0 - MU0_FIRST));
-                        if (idx < M && kept >= 0)
+#pragma unroll
+                        for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
                         {
-                            const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
-                            __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + kept);
+                            const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
+                            if (idx < M)
+                            {
+                                const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
+                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                            }
+                        }
+                    }
+                }
+                else
+                {
+                    KeepEvery ke;
+                    ke.init(blk, (unsigned)LOUT, chan.sub);
+                    if (cl < nch && !(diag & 2))
+                    {
+#pragma unroll
+                        for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                        {
+                            const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
+                            const int64_t kept = ke.index((unsigned)(2 * (lane >> 2) + (lane & 1)) + 32u * (unsigned)(mu0 - MU0_FIRST));
+                            if (idx < M && kept >= 0)
+                            {
+                                const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
+                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + kept);
+                            }
                         }
                     }
                 }
@@ -2213,7 +2252,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     buf_store(csrd, voff, (mu0 - MU0_FIRST) * 512, cmul_v<false>(c[mu0], wl));
             }
         }
-        else if constexpr (CHAN == 5)
+        else if constexpr (CHAN == 5 || CHAN == 6)
         {
             // ---- filter bank at decimation 4, every channel at its own centre bin (round 4) ---------------------------------------
             // The slot form above with the table entries of kappa (k_low - b = kappa - 256 cy, gathered from the lane that holds kappa)
@@ -2228,7 +2267,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     t[j] = r[phys(i, j)];
-                static_assert(CHAN != 5 || TAN, "the general form at decimation 4 is written for the (cos, tan) image");
+                static_assert((CHAN != 5 && CHAN != 6) || TAN, "the general form at decimation 4 is written for the (cos, tan) image");
                 const cf e1 = tw1[(i * 3 + 0) * 64 + lane], e2 = tw1[(i * 3 + 1) * 64 + lane], e3 = tw1[(i * 3 + 2) * 64 + lane];
 #pragma unroll
                 for (int m0 = 0; m0 < 4; m0++)
@@ -2288,17 +2327,27 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 const f2v *rowp = rowt + ch * 16;
                 // decimation 12, 20, 28, ... (4 x sub): every sub-th output of this tail is a real output (KeepEvery, as in the
                 // single-channel tail; sub = 1: all of them).  Descriptor over the kept outputs from this block's first one on.
-                KeepEvery ke;
-                ke.init(blk, (unsigned)LOUT, chan.sub);
-                const int64_t qb = ke.qU + (ke.rem ? 1 : 0);
-                const srd_t csrd = make_srd(chan.out[ch] + qb, (diag & 2) ? 0 : (decn_m - qb) * 8);
-                const int lim = (int)((M - obase) < 65536 ? (M - obase) : 65536); // tail outputs of the call left from this block on
-#pragma unroll
-                for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                if constexpr (CHAN == 5) // (decimation 4 itself; its own instantiation: with both store loops in one kernel it ran 4 % slower)
                 {
-                    const int64_t kept = ke.index((unsigned)lane + 64u * (unsigned)(mu0 - MU0_FIRST));
-                    const unsigned so = (kept >= 0 && lane + 64 * (mu0 - MU0_FIRST) < lim) ? (unsigned)(kept - qb) * 8u : 0xffffffffu;
-                    buf_store(csrd, so, 0, cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST])));
+                    const srd_t csrd = make_srd(chan.out[ch] + obase, (diag & 2) ? 0 : (M - obase) * 8);
+#pragma unroll
+                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                        buf_store(csrd, voff, (mu0 - MU0_FIRST) * 512, cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST])));
+                }
+                else
+                {
+                    KeepEvery ke;
+                    ke.init(blk, (unsigned)LOUT, chan.sub);
+                    const int64_t qb = ke.qU + (ke.rem ? 1 : 0);
+                    const srd_t csrd = make_srd(chan.out[ch] + qb, (diag & 2) ? 0 : (decn_m - qb) * 8);
+                    const int lim = (int)((M - obase) < 65536 ? (M - obase) : 65536); // tail outputs of the call left from this block on
+#pragma unroll
+                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
+                    {
+                        const int64_t kept = ke.index((unsigned)lane + 64u * (unsigned)(mu0 - MU0_FIRST));
+                        const unsigned so = (kept >= 0 && lane + 64 * (mu0 - MU0_FIRST) < lim) ? (unsigned)(kept - qb) * 8u : 0xffffffffu;
+                        buf_store(csrd, so, 0, cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST])));
+                    }
                 }
             }
         }
@@ -2606,7 +2655,7 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     // (decimation 4 sub behind the decimate-by-4 tail, CHAN == 1: the tail runs at the fs/4 rate and keeps every sub-th output)
     constexpr int F = (CHAN == 16 || CHAN == 17) ? 16 : (CHAN == 8 || CHAN == 9) ? 8 : (CHAN == 2 || CHAN == 3) ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
     ChanArgs ca = a.chan ? *a.chan : ChanArgs{};
-    ca.sub = (CHAN == 1 || CHAN == 5) ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : CHAN == 9 ? (ca.sub & 1u) /* the parity */
+    ca.sub = (CHAN == 1 || CHAN == 5 || CHAN == 6) ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : CHAN == 9 ? (ca.sub & 1u) /* the parity */
              : (CHAN == 8 && NCO) ? (uint32_t)(a.D / 8) : CHAN == 17 ? (uint32_t)(a.D / 16) : 1u; // (general bank forms: D = F x sub)
     const int64_t m_rate = DECN ? a.N : CHAN == 9 ? a.M : (a.M - 1) * (int64_t)ca.sub + 1; // (CHAN 9: `sub` carries the slot parity)
     const int32_t n0_rate = DECN ? 0 : a.n0;
@@ -2874,8 +2923,10 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             case 2: return launch_fft_t<ROWS, true, true, false, 16>(a);
             default: return launch_fft_t<ROWS, true, true, true, 16>(a);
             }
-        if (a.chan->general) // decimation 4, every channel at its own centre
+        if (a.chan->general && a.D == 4) // decimation 4, every channel at its own centre
             return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 5>(a) : launch_fft_t<ROWS, true, false, false, 5>(a);
+        if (a.chan->general) // decimation 12, 20, 28, ...: the same tail keeping every (D / 4)-th output
+            return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 6>(a) : launch_fft_t<ROWS, true, false, false, 6>(a);
         return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 4>(a) : launch_fft_t<ROWS, true, false, false, 4>(a);
     }
     if (a.D == 2 && !a.no_fold) // frequency-domain fold + 2048-point inverse (round 3)
