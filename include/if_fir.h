@@ -158,7 +158,7 @@ uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOu
  * ppDevOut[c]: 16-byte aligned device buffers of if_fir_out_count() samples each.  Asynchronous on the context's stream
  * like if_fir_process_device.  (Decimation 8, no NCO on the context: four or more channels on even -- or on odd -- slots, no
  * slot listed twice, are computed together from one pair of 8-point transforms per group, whatever their number; a call is then
- * up to three kernel launches on the context's stream.  Results do not depend on the route beyond float32 rounding.) */
+ * up to two kernel launches on the context's stream.  Results do not depend on the route beyond float32 rounding.) */
 uint8_t if_fir_channelizer_process_device(if_fir_ctx_t *pCtx, uint32_t ulChannels, const uint32_t *pulSlots,
                                           const void *pDevIn, void *const *ppDevOut, uint64_t ullSamples,
                                           uint64_t *pullOutSamples);

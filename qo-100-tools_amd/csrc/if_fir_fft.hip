@@ -1198,6 +1198,10 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         return;
     }
     cf r[64];
+    // CHAN 9 with both slot parities in ONE launch (chan.sub bit 1; round 4): the queue hands out VIRTUAL blocks 2 b + parity -- block b of
+    // the stream is transformed twice, by neighbouring waves of a workgroup, and the second read of its rows is served by L2
+    const bool both = (CHAN == 9) && ((chan.sub & 2u) != 0u);
+    auto rb = [&](int64_t b) -> int64_t { return (CHAN == 9 && both) ? (b >> 1) : b; }; // virtual block -> block of the stream
     bool loaded = false; // the rows of `blk` are already in flight (issued by the prologue or the previous iteration's epilogue)
     // ---- first block: static (wave w of workgroup b takes block w of global group b), and its rows are requested BEFORE
     //      the table copy below, so that the two transfers overlap at the head of the launch
@@ -1206,7 +1210,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     if (plain_start)
     {
         blk = (int64_t)blockIdx.x * FFT_WAVES + wid; // slot wid of local group 0 = global group blockIdx.x
-        const int64_t s0 = blk * L - OVL + n0 - in_shift;
+        const int64_t s0 = rb(blk) * L - OVL + n0 - in_shift;
         if (blk < nblocks && s0 >= 0 && !(diag & 1))
         {
             const srd_t srd = make_srd(in + s0 * ISZ, (N - s0) * ISZ);
@@ -1355,7 +1359,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     while (blk < nblocks)
     {
         FFT_STAMP(0);
-        const int64_t s0 = blk * L - OVL + n0 - in_shift; // stream index of the block's first sample (n0: decimation phase)
+        const int64_t s0 = rb(blk) * L - OVL + n0 - in_shift; // stream index of the block's first sample (n0: decimation phase)
         if (!loaded && !(diag & 1))
         {
             if (s0 >= 0)
@@ -1475,13 +1479,13 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             // profiles/r04_end_game.txt.)
             blk_next = queue_take(dq, simd, nblocks_main, nblocks);
         }
-        const int64_t s0n = blk_next * L - OVL + n0 - in_shift;
+        const int64_t s0n = rb(blk_next) * L - OVL + n0 - in_shift;
         const bool next_fast = (blk_next < nblocks) && (s0n >= 0) && !(diag & 1);
         // diag 16: every wave fetches the same (cached) block -> separates HBM effects from the instruction stream's
         const int64_t s0f = (diag & 16) ? (int64_t)(lane & 0) : s0n;
         const srd_t nsrd = make_srd(in + (next_fast ? s0f : 0) * ISZ, next_fast ? (N - s0f) * ISZ : 0);
         // outputs beyond M are dropped by the descriptor's bounds check
-        const int64_t obase = blk * LOUT;
+        const int64_t obase = rb(blk) * LOUT;
         const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
         // filter-bank tails with an NCO: the block's share of the output rotation, phasor(phi0 + delta obase), wave-uniform;
         // parked in a per-wave LDS word until the tails need it (the 16-slot tail has neither SGPRs nor VGPRs to spare)
@@ -1866,7 +1870,11 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             // and two 8-point transforms per group serve eight channels: 88 packed instructions where the per-channel form spends
             // 8 x 60.  The inverses follow two slots at a time exactly as in the per-channel form; every lane stores to its slot's
             // buffer (pointer table in LDS, as in the 16-slot bank); slots nobody asked for are not inverted.
-            const int par = (int)chan.sub & 1; // (the launcher passes the parity in `sub`)
+            // (the launcher passes the parity in `sub`; both parities in one launch: the virtual block's low bit -- then the ODD slots
+            // take the even slots' image with the halves exchanged and the eight constants W16^a on top, so one image serves both)
+            const int par = both ? (int)(blk & 1) : ((int)chan.sub & 1);
+            const bool swap = both && par;
+            const int h0 = swap ? 8 : 0, h1 = swap ? 0 : 8;
 #pragma unroll
             for (int i = 0; i < 4; i++)
             {
@@ -1879,8 +1887,19 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int a8 = 0; a8 < 8; a8++)
                 {
                     const cf u = r[phys(i, a8)], vb = tw_u<false>(r[phys(i, a8 + 8)], e8);
-                    t0[a8] = cmul_v<false>(tw_ac<false>(u, vb, e8), hp[(i * 16 + a8) * 64 + lane]);     // w0 . (b^a G_par W16^(a par)): first half of the image
-                    t1[a8] = cmul_v<false>(tw_ac<true>(u, vb, e8), hp[(i * 16 + 8 + a8) * 64 + lane]); // w1 . (b^a G_(1 - par) W16^(a par)): second half
+                    t0[a8] = cmul_v<false>(tw_ac<false>(u, vb, e8), hp[(i * 16 + h0 + a8) * 64 + lane]); // w0 . (b^a G_par W16^(a par)): first half of the image
+                    t1[a8] = cmul_v<false>(tw_ac<true>(u, vb, e8), hp[(i * 16 + h1 + a8) * 64 + lane]);  // w1 . (b^a G_(1 - par) W16^(a par)): second half
+                }
+                if (swap) // (wave-uniform) W16^a, a = 1..7
+                {
+                    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+                    t0[1] = cmul_s<false>(t0[1], (cf){C1, -S1}); t1[1] = cmul_s<false>(t1[1], (cf){C1, -S1});
+                    t0[2] = cmul_s<false>(t0[2], (cf){R, -R});   t1[2] = cmul_s<false>(t1[2], (cf){R, -R});
+                    t0[3] = cmul_s<false>(t0[3], (cf){S1, -C1}); t1[3] = cmul_s<false>(t1[3], (cf){S1, -C1});
+                    t0[4] = (cf){t0[4].y, -t0[4].x};             t1[4] = (cf){t1[4].y, -t1[4].x}; // -j
+                    t0[5] = cmul_s<false>(t0[5], (cf){-S1, -C1}); t1[5] = cmul_s<false>(t1[5], (cf){-S1, -C1});
+                    t0[6] = cmul_s<false>(t0[6], (cf){-R, -R});  t1[6] = cmul_s<false>(t1[6], (cf){-R, -R});
+                    t0[7] = cmul_s<false>(t0[7], (cf){-C1, -S1}); t1[7] = cmul_s<false>(t1[7], (cf){-C1, -S1});
                 }
                 fft8<false>(t0);
                 fft8<false>(t1);
@@ -2655,11 +2674,11 @@ static hipError_t launch_fft_t(const LaunchArgs &a)
     // (decimation 4 sub behind the decimate-by-4 tail, CHAN == 1: the tail runs at the fs/4 rate and keeps every sub-th output)
     constexpr int F = (CHAN == 16 || CHAN == 17) ? 16 : (CHAN == 8 || CHAN == 9) ? 8 : (CHAN == 2 || CHAN == 3) ? 2 : DEC4 ? 4 : 1; // the tail's own decimation
     ChanArgs ca = a.chan ? *a.chan : ChanArgs{};
-    ca.sub = (CHAN == 1 || CHAN == 5 || CHAN == 6) ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : CHAN == 9 ? (ca.sub & 1u) /* the parity */
+    ca.sub = (CHAN == 1 || CHAN == 5 || CHAN == 6) ? (uint32_t)(a.D / 4) : CHAN == 3 ? (uint32_t)(a.D / 2) : CHAN == 9 ? (ca.sub & 3u) /* bit 0: the parity, bit 1: both parities */
              : (CHAN == 8 && NCO) ? (uint32_t)(a.D / 8) : CHAN == 17 ? (uint32_t)(a.D / 16) : 1u; // (general bank forms: D = F x sub)
     const int64_t m_rate = DECN ? a.N : CHAN == 9 ? a.M : (a.M - 1) * (int64_t)ca.sub + 1; // (CHAN 9: `sub` carries the slot parity)
     const int32_t n0_rate = DECN ? 0 : a.n0;
-    const int64_t nblocks = a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0;
+    const int64_t nblocks = (a.M > 0 ? (m_rate + LOUT - 1) / LOUT : 0) * ((CHAN == 9 && (ca.sub & 2u)) ? 2 : 1); // (both parities: virtual blocks)
     if (nblocks <= 0)
         return hipSuccess;
     const int64_t wgs_max = (a.grid_limit > 0 && a.grid_limit < ncus) ? a.grid_limit : ncus;
@@ -2859,13 +2878,32 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             // Channels on the slot grid.  A parity (even / odd slots) with at least four channels, none listed twice, runs the
             // ALL-SLOTS form (round 4): one launch computes the eight slots of that parity from two 8-point transforms per group
             // (2340 packed instructions a block whatever the count, against 1008 + 415 per channel) and stores the wanted ones; the
-            // other channels keep the per-channel form.  Up to three launches per call on the context's stream; only the first
+XX
             // one writes the next call's history.  (Even slots: the bank's own table image; odd slots: fft_tables_b.)
             const ChanArgs &cin = *a.chan;
             uint32_t pmask[2], rest = 0;
             // (diag 4096, development: per-channel form only)
             fft_bank8_plan(cin.slot, cin.count, a.fft_tables_b != nullptr && !(a.diag & 4096), pmask, &rest);
             bool first = true;
+            if (pmask[0] && pmask[1] && !(a.diag & 8192)) // both parities: ONE launch over virtual blocks (diag 8192, development: two launches)
+            {
+                ChanArgs cs{};
+                cs.count = (uint32_t)__builtin_popcount(pmask[0] | pmask[1]);
+                cs.sub = 2u;
+                cs.rot_e = cin.abs0n0 & 15u;
+                cs.abs0n0 = cin.abs0n0;
+                cs.mask16 = pmask[0] | pmask[1];
+                for (uint32_t c = 0; c < cin.count; c++)
+                    if ((cs.mask16 >> (cin.slot[c] & 15u)) & 1u)
+                        cs.out[cin.slot[c] & 15u] = cin.out[c];
+                LaunchArgs p = a;
+                p.chan = &cs;
+                const hipError_t e = a.in_i16 ? launch_fft_t<ROWS, true, true, false, 9>(p) : launch_fft_t<ROWS, true, false, false, 9>(p);
+                if (e != hipSuccess)
+                    return e;
+                first = false;
+                pmask[0] = pmask[1] = 0;
+            }
             for (uint32_t par = 0; par < 2; par++)
             {
                 if (!pmask[par])

@@ -846,12 +846,15 @@ def test_filter_bank_at_decimation_8_and_16(fir, oracle, torch_cuda, monkeypatch
     subsets = ((list(range(16)), 0), ([5, 0, 15, 8, 3, 10, 1, 14], 0), ([7, 2], 2001))
     if d == 8:
         # round 4: a parity (even / odd slots) with >= 4 channels, no slot twice, runs the ALL-SLOTS form (two 8-point transforms
-        # per group give the eight slots of that parity; the rest keep the per-channel form: up to three launches a call)
+        # per group give the eight slots of that parity; both parities: ONE launch over virtual blocks 2 b + parity; the rest keep the
+        # per-channel form: up to two launches a call)
         subsets = ((list(range(16)), 0), ([5, 0, 15, 8, 3, 10, 3], 0), ([7], 2001),
                    ([1, 5, 9, 13, 2], 0),                       # odd slots all-slots + one even channel per-channel
                    ([0, 2, 4, 6, 8, 10, 12, 14], 2001),         # even slots, one-workgroup grid (run queue)
                    ([3, 1, 15, 13, 11, 9, 7, 5, 0, 4], 0),      # all odd slots + two even ones
-                   ([14, 3, 8, 6, 0], 1004096))                 # (development launch 4096: per-channel form although 4 even)
+                   ([14, 3, 8, 6, 0], 1004096),                 # (development launch 4096: per-channel form although 4 even)
+                   (list(range(16)), 1008192),                  # (development launch 8192: the two parities as two launches, not one)
+                   ([1, 0, 3, 2, 5, 4, 7, 6, 15], 2001))        # both parities in one launch (virtual blocks), one-workgroup grid
     with fir.IfFir(taps, d, n, dev=True) as f:
         if i16:
             f.set_input_format(fir.INPUT_I16)
