@@ -2878,7 +2878,8 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             // Channels on the slot grid.  A parity (even / odd slots) with at least four channels, none listed twice, runs the
             // ALL-SLOTS form (round 4): one launch computes the eight slots of that parity from two 8-point transforms per group
             // (2340 packed instructions a block whatever the count, against 1008 + 415 per channel) and stores the wanted ones; the
-XX
+            // other channels keep the per-channel form.  Both parities qualifying: ONE launch over virtual blocks (kernel).  Up to two
+            // launches per call on the context's stream; only the first
             // one writes the next call's history.  (Even slots: the bank's own table image; odd slots: fft_tables_b.)
             const ChanArgs &cin = *a.chan;
             uint32_t pmask[2], rest = 0;
