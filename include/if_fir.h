@@ -151,7 +151,8 @@ uint8_t if_fir_device_info(const if_fir_ctx_t *pCtx, char *pszOut, uint32_t ulOu
  * context's decimation: the result of ulChannels contexts with if_fir_set_nco(slot/16.0), computed in ONE pass over the input.
  * The context must have <= 3073 taps, float32 or int16 input, run on the overlap-save backend and have decimation 4 (fs/16
  * channels 4x oversampled; no NCO), 8 (2x oversampled) or 16 (the channel rate: all 16 slots come out of one
- * forward transform; the wanted ones are stored).  At decimation 8 and 16 the context may carry an NCO: it shifts the WHOLE
+ * forward transform; the wanted ones are stored); every other multiple of 4 up to 64 is served through the per-channel forms
+ * of if_fir_channelizer_process_device_freq (slot s = centre s/16).  At decimation 8 and 16 the context may carry an NCO: it shifts the WHOLE
  * slot grid (channel c is centred at pulSlots[c]/16 + f_nco: a common fine offset).
  * The context's streaming state (history, decimation phase, sample index) is shared
  * by all channels.  ulChannels 1..16, slots 0..15: any subset, repeats allowed (decimation 16: each slot at most once);

@@ -739,7 +739,10 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
         set_err(pCtx, "if_fir_channelizer_process_device: 1..%d channels with slot (or centre) and output arrays", if_fir::CHAN_MAX);
         return 0;
     }
-    const int fb = if_fir::fft_bank_tail((int)pCtx->D, pdFreq != nullptr); // the bank's tail: 4, 8 or 16 (0: decimation not served)
+    // decimation 4, 8, 16: the slot forms; every other multiple of 4 up to 64 runs behind one of their tails keeping every (D / tail)-th
+    // output -- through the per-channel general forms, also for channels given as slots (centre bin 256 slot)
+    const bool thin = pCtx->D != 4 && pCtx->D != 8 && pCtx->D != 16;
+    const int fb = if_fir::fft_bank_tail((int)pCtx->D, pdFreq != nullptr || thin); // the bank's tail: 4, 8 or 16 (0: decimation not served)
     if (pdFreq && (!fb || pCtx->nco_word))
     {
         set_err(pCtx, "if_fir_channelizer_process_device_freq: needs a context with decimation 4, 8, 12, ..., 64 (a multiple of 4) and no "
@@ -749,7 +752,8 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
     if (!fb || (fb == 4 && pCtx->nco_word) ||
         !if_fir::fft_supported(pCtx->T, pCtx->D) || if_fir::fft_two_partitions(pCtx->T))
     {
-        set_err(pCtx, "if_fir_channelizer_process_device: needs <= 3073 taps and decimation 4 (no NCO), 8 or 16");
+        set_err(pCtx, "if_fir_channelizer_process_device: needs <= 3073 taps and a decimation that is a multiple of 4 up to 64 (no NCO "
+                      "at 4, 12, 20, ...)");
         return 0;
     }
     if (pCtx->backend != IF_FIR_BACKEND_HIP_FFT)
@@ -760,7 +764,7 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
     }
     if_fir::ChanArgs chan{};
     chan.count = ulChannels;
-    chan.general = pdFreq ? 1u : 0u;
+    chan.general = (pdFreq || thin) ? 1u : 0u;
     for (uint32_t c = 0; c < ulChannels; c++)
     {
         if (pdFreq)
@@ -810,7 +814,7 @@ static uint8_t channelizer_run(if_fir_ctx_t *pCtx, uint32_t ulChannels, const ui
         // its effective complex taps) joins the slot's mix-down word
         chan.bin[c] = 256u * pulSlots[c];
         chan.pword[c] = (pulSlots[c] << 28) + pCtx->nco_word;
-        for (int m0 = 1; m0 < 8; m0++) // decimation 4 uses the first three
+        for (int m0 = 1; m0 < 16; m0++) // decimation 4 uses the first three, 8 the first seven
         {
             const double a = -2.0 * M_PI * (double)((m0 * pulSlots[c]) & 15u) / 16.0; // W16^(m0 slot) = W4096^(m0 bin)
             chan.tw[c][2 * (m0 - 1) + 0] = (float)cos(a);
