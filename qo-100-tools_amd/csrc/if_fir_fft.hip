@@ -1164,7 +1164,6 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     static_assert(CHAN == 0 || ((CHAN == 1 || CHAN == 2 || CHAN == 3 || CHAN == 4 || CHAN == 5 || CHAN == 6 || CHAN == 8 || CHAN == 9 || CHAN == 16 || CHAN == 17) && DEC4),
                   "decimating tails: 1, 2, 3, or the bank at 4 (4: slots, 5: any centre), 8 (8: per channel, 9: all slots of a parity), 16 (16: all slots, 17: per channel)");
     static_assert((CHAN != 5 && CHAN != 6) || !NCO, "channels at their own centres: no common offset on top");
-    static_assert(CHAN != 9 || !NCO, "the all-slots form serves channels on the slot grid");
     static_assert(CHAN != 17 || !NCO, "channels at their own centres: no common offset on top");
     static_assert(CHAN != 4 || !NCO, "the decimate-by-4 bank takes no NCO (a single channel with an NCO is the DEC4 kernel)");
     // 2 overlap rows (<= 129 taps, round 4): the full-rate pipeline only -- the decimating tails drop whole 64-output rows of the
@@ -1489,7 +1488,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         const srd_t osrd = make_srd(out + obase, (diag & 2) ? 0 : (M - obase) * 8);
         // filter-bank tails with an NCO: the block's share of the output rotation, phasor(phi0 + delta obase), wave-uniform;
         // parked in a per-wave LDS word until the tails need it (the 16-slot tail has neither SGPRs nor VGPRs to spare)
-        if constexpr (NCO && CHAN == 16)
+        if constexpr (NCO && (CHAN == 16 || CHAN == 9))
         {
             const float2 pb = nco_phasor(nco_phi0 + nco_delta * (uint32_t)obase);
             if (lane == 0)
@@ -1952,6 +1951,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     cf wl = ncob[16 + ((sl * (int)chan.rot_e) & 15)];
                     if ((sl & lane) & 1)
                         wl = (cf){-wl.x, -wl.y};
+                    // NCO (the context's NCO = a common fine offset of the whole slot grid, as in the 16-slot tail): output m = obase +
+                    // 32 (mu0 - first) + 2 mu1 + mu2 is also rotated by phasor(phi0 + delta m) = [block, per-wave LDS word] * [lane:
+                    // table entries 32..63] * [row: entries 0..15]
+                    if constexpr (NCO)
+                        wl = cmul_v<false>(cmul_v<false>(wl, *reinterpret_cast<const cf *>(smem + LDS_QNCO + wid * 8)),
+                                           ncob[32 + 2 * (lane >> 2) + (lane & 1)]);
                     const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
                     if (po != nullptr && !(diag & 2))
                     {
@@ -1960,7 +1965,14 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         {
                             const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
                             if (idx < M)
-                                __builtin_nontemporal_store(cmul_v<false>(c[mu0], wl), reinterpret_cast<cf *>(po) + idx);
+                            {
+                                cf v;
+                                if constexpr (NCO)
+                                    v = cmul_v<false>(c[mu0], cmul_v<false>(wl, ncob[mu0 - MU0_FIRST]));
+                                else
+                                    v = cmul_v<false>(c[mu0], wl);
+                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
+                            }
                         }
                     }
                 }
@@ -2851,6 +2863,19 @@ hipError_t launch_fft_rows(const LaunchArgs &a); // defined and explicitly insta
 hipError_t launch_fft_two_partitions(const LaunchArgs &a); // (in the 32-row unit)
 #ifdef IF_FIR_FFT_ROWS
 template <int ROWS>
+static hipError_t launch_all_slots(const LaunchArgs &p, bool nco) // the decimation-8 bank's all-slots form (tail 9)
+{
+    if constexpr (ROWS >= 4)
+        switch ((p.in_i16 ? 2 : 0) | (nco ? 1 : 0))
+        {
+        case 0: return launch_fft_t<ROWS, true, false, false, 9>(p);
+        case 1: return launch_fft_t<ROWS, true, false, true, 9>(p);
+        case 2: return launch_fft_t<ROWS, true, true, false, 9>(p);
+        default: return launch_fft_t<ROWS, true, true, true, 9>(p);
+        }
+    return hipErrorInvalidConfiguration;
+}
+template <int ROWS>
 hipError_t launch_fft_rows(const LaunchArgs &a)
 {
     int F = 1;
@@ -2870,11 +2895,12 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
         {
             // slot form (chan->tw[] = W16^(a slot), a = 1..7) when every channel sits on the fs/16 grid and the context has no NCO;
             // the general form (chan->bin[] / pword[]: centre bin and mix-down word of a channel) otherwise
-            bool general = a.nco_word != 0 || a.chan->general;
+            bool general = a.chan->general || a.D != 8;
             for (uint32_t c = 0; c < a.chan->count; c++)
-                general = general || (a.chan->bin[c] & 255u) || a.chan->pword[c] != (a.chan->bin[c] << 20);
+                general = general || (a.chan->bin[c] & 255u) || a.chan->pword[c] != (a.chan->bin[c] << 20) + a.nco_word;
             if (general)
                 return a.in_i16 ? launch_fft_t<ROWS, true, true, true, 8>(a) : launch_fft_t<ROWS, true, false, true, 8>(a);
+            const bool nco = a.nco_word != 0; // channels on the slot grid shifted by the context's NCO (a common offset)
             // Channels on the slot grid.  A parity (even / odd slots) with at least four channels, none listed twice, runs the
             // ALL-SLOTS form (round 4): one launch computes the eight slots of that parity from two 8-point transforms per group
             // (2340 packed instructions a block whatever the count, against 1008 + 415 per channel) and stores the wanted ones; the
@@ -2899,7 +2925,7 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
                         cs.out[cin.slot[c] & 15u] = cin.out[c];
                 LaunchArgs p = a;
                 p.chan = &cs;
-                const hipError_t e = a.in_i16 ? launch_fft_t<ROWS, true, true, false, 9>(p) : launch_fft_t<ROWS, true, false, false, 9>(p);
+                const hipError_t e = launch_all_slots<ROWS>(p, nco);
                 if (e != hipSuccess)
                     return e;
                 first = false;
@@ -2923,7 +2949,7 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
                 p.fft_tables = par ? a.fft_tables_b : a.fft_tables; // (even slots: the bank's own image; odd slots: the image behind it)
                 if (!first)
                     p.hist_out = nullptr;
-                const hipError_t e = a.in_i16 ? launch_fft_t<ROWS, true, true, false, 9>(p) : launch_fft_t<ROWS, true, false, false, 9>(p);
+                const hipError_t e = launch_all_slots<ROWS>(p, nco);
                 if (e != hipSuccess)
                     return e;
                 first = false;
@@ -2950,6 +2976,8 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
             p.chan = &cl;
             if (!first)
                 p.hist_out = nullptr;
+            if (nco) // (the slot form proper has no NCO: the left-over channels of a shifted grid take the general form)
+                return a.in_i16 ? launch_fft_t<ROWS, true, true, true, 8>(p) : launch_fft_t<ROWS, true, false, true, 8>(p);
             return a.in_i16 ? launch_fft_t<ROWS, true, true, false, 8>(p) : launch_fft_t<ROWS, true, false, false, 8>(p);
         }
         if (Fb == 16 && a.chan->general) // every channel at its own centre (per channel; arrays indexed by channel)

@@ -2,7 +2,7 @@
 """fbank_bench.py — uniform filter bank (if_fir_channelizer_process_device) against the same channels
 computed one at a time (if_fir_set_nco contexts): time per pass over a 2^log2n-sample wideband stream, whole-output
 comparison of every channel, one JSON line.
-usage: python tools/fbank_bench.py [channels=8] [log2n=28] [taps=255] [decimation=4] [freq] [tuning=N]   (decimation 4: 4x oversampled fs/16
+usage: python tools/fbank_bench.py [channels=8] [log2n=28] [taps=255] [decimation=4] [freq] [tuning=N] [nco=F]   (decimation 4: 4x oversampled fs/16
 channels; 16: the channel rate, all 16 slots from one forward transform, round 3; "freq" (decimation 4, 8 or 16, round 4): the channels sit
 at arbitrary centres on the fs/4096 grid -- if_fir_channelizer_process_device_freq -- instead of on slots)"""
 import json
@@ -23,6 +23,7 @@ def main():
     dec = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     freq = "freq" in sys.argv[5:]
     tuning = [int(a[7:]) for a in sys.argv[5:] if a.startswith("tuning=")]   # e.g. tuning=1004096: decimation 8 without the all-slots form
+    nco = ([float(a[4:]) for a in sys.argv[5:] if a.startswith("nco=")] or [0.0])[0]   # the context's NCO: a common offset of the slot grid (decimation 8 / 16)
     n = 1 << log2n
     if tuning:
         os.environ["IF_FIR_DEBUG"] = "1"
@@ -41,6 +42,8 @@ def main():
     with fir.IfFir(taps, dec, 0, dev=True) as f:
         if tuning:
             f.set_tuning(tuning[0])
+        if nco:
+            f.set_nco(nco)
         m = f.out_count(n)
         outs = [torch.empty(2 * m, dtype=torch.float32, device="cuda") for _ in range(nch)]
         torch.cuda.synchronize()
@@ -71,7 +74,8 @@ def main():
     ms_single = 0.0
     for c, s in enumerate(slots):
         with fir.IfFir(taps, dec, 0, dev=True) as f1:
-            f1.set_nco(centres[c] if freq else (s / 16.0 if s <= 8 else s / 16.0 - 1.0))   # slots above 8 are negative frequencies
+            fs = centres[c] if freq else (s / 16.0 if s <= 8 else s / 16.0 - 1.0) + nco   # slots above 8 are negative frequencies
+            f1.set_nco(fs - 1.0 if fs > 0.5 else fs + 1.0 if fs < -0.5 else fs)
             f1.set_stream(stream.cuda_stream)
             f1.process_device(x.data_ptr(), ref.data_ptr(), n)
             f1.synchronize()
