@@ -604,3 +604,21 @@ def test_filter_bank_table_images(fir):
         for n2 in range(16):
             g = sum(H[klow + 256 * k2] * W(16, n2 * k2) for k2 in range(16)) * W(4096, n2 * klow)
             assert np.max(np.abs(g16[(i * 16 + n2) * 64 + lane] - g)) <= 2e-7 * scale * 2, (i, n2)
+
+
+def test_host_table_builders_under_sanitizers(tmp_path):
+    """The HOST side of csrc/if_fir_fft.hip -- fft_build_tables for every image (single-channel, full-rate, bank 8 even / odd, bank
+    16), fft_build_tables_odd, the decimation-8 routing -- compiled with AddressSanitizer + UBSan (CPU only: hipcc --offload-host-only)
+    and run over taps 1 ... 4096, real and complex, into heap buffers of exactly the documented sizes (tests/c/host_tables_asan.cpp)."""
+    import subprocess
+    src = os.path.join(ROOT, "qo-100-tools_amd", "csrc", "if_fir_fft.hip")
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "qo-100-tools_amd", "csrc")]
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17"]
+    obj = str(tmp_path / "fft_host.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-host-only"] + san + inc + ["-c", src, "-o", obj])
+    exe = str(tmp_path / "host_asan")
+    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++"] + san + inc + ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                           os.path.join(ROOT, "tests", "c", "host_tables_asan.cpp"), obj, "-o", exe,
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0 and "host table builders: clean" in run.stdout, (run.stdout[-2000:], run.stderr[-4000:])
