@@ -370,42 +370,111 @@ __device__ __forceinline__ void exchange1_inv(cf (&r)[64])
             swap32(r[4 * k0 + rho], r[4 * (k0 + 8) + rho]);
 }
 
-// Lanes exchange data through LDS in several places below: one phase of writes, one of reads.  The hardware executes a wave's LDS
-// instructions in order, but for the COMPILER these are plain loads and stores of one thread: where it can prove that a read
-// never overlaps the thread's own writes it may move it across them (round 4: it did, in the odd-decimation kernel's
-// transposition, which therefore carries a compiler fence).  In the exchanges below that proof is impossible because it would be
-// false: a lane really reads back addresses it has written (exchange2: element j of lane (g, m) goes to g XREG + j XROW + 8 m and
-// the lane reads g XREG + m XROW + 8 j' -- the same address for j = j' = m; the small transposes likewise), so the single-thread
-// order of the language already pins every read behind the writes.  IF_FIR_FFT_LDS_FENCE=1 adds a fence all the same; it costs
-// 0.65 % on the headline (profiles/r04_lds_fence_ab.txt) and is off.
-#ifndef IF_FIR_FFT_LDS_FENCE
-#define IF_FIR_FFT_LDS_FENCE 0
-#endif
-#if IF_FIR_FFT_LDS_FENCE
-#define LDS_FENCE() asm volatile("" ::: "memory")
-#else
-#define LDS_FENCE() (void)0
-#endif
-
-// 16x16 transposition inside each 16-lane row: element (i, j) of lane (g, m) -> lane (g, j), slot (i, m)
-__device__ __forceinline__ void exchange2(cf (&r)[64], char *xb, int lane)
+// ---- lane exchanges through LDS: the order of their phases is a property of the BUILD (round 5) -----------------
+// Lanes exchange data through the wave's private LDS buffer in several places below: one phase of 16 writes per lane, one of 16
+// reads, then the next exchange's writes into the same buffer.  The hardware executes a wave's LDS instructions in order, but for
+// the COMPILER these are plain loads and stores of ONE thread, and it may reorder a load and a store whenever it can prove that
+// they never overlap.  For most pairs of these exchanges such a proof exists: in exchange2 write j goes to base + 8 m + 136 j and
+// read j' comes from base + 136 m + 8 j'; the difference is 128 m + 8 (j' - j) - 128 j, i.e. 8 (j' - j) modulo 128 -- never within
+// 8 bytes of 0 for j != j', exactly the variable-scale / constant-offset test of LLVM's BasicAA (only the pair j = j' = m really
+// overlaps).  So read j' could legally be placed ahead of writes j' + 1 .. 15, and the next exchange's write j ahead of this one's
+// reads -- and then a lane reads a slot its partner lane has not written yet, or has overwritten already.  Round 4 saw exactly that
+// in the odd-decimation kernel's transposition (garbage outputs) and answered with a compiler fence there; the other exchanges
+// were in order "today" and had the fence switched off because it cost 0.65 % on the headline (it pins the table reads too).
+// Round 5, two measures that cost nothing at run time:
+//  (1) every exchange READ goes through a base address that has passed through an empty `asm volatile` (lds_opaque): the compiler
+//      knows nothing about its value, no alias-freedom proof against any LDS store exists any more, and the single-thread
+//      semantics of the language pin every exchange read behind the writes before it and every later exchange write behind the
+//      read -- while the table reads (plain, read-only data) stay free to move, which is what the blunt fence took away;
+//  (2) the build checks the result: all exchange accesses are made by the two helpers below (xst16 / xld16); the units are compiled with
+//      line tables (-gline-tables-only: no effect on the generated code), and tools/check_lds_exchange.py walks every kernel's
+//      disassembly, classifies each DS instruction by its source line and fails the build unless the exchange stream is strictly
+//      16 stores, 16 loads, 16 stores, ... (csrc/Makefile; tests/test_host.py compiles a deliberately mis-ordered probe,
+//      -DIF_FIR_FFT_LDSX_PROBE=1, and sees it flagged).
+__device__ __forceinline__ const char *lds_opaque(const char *p)
+{
+    // (the asm operand is the 32-bit LDS pointer itself, not an integer: an inttoptr would be re-materialised next to every load
+    // by the address-sinking pass and the load-store vectorizer would no longer see one base -- no ds_read2_b64)
+    const __attribute__((address_space(3))) char *q = (const __attribute__((address_space(3))) char *)p;
+    asm volatile("" : "+v"(q));
+    return (const char *)q;
+}
+// One phase of an exchange: element j at p + j STRIDE.  (The empty asm on the loaded values emits nothing; it keeps the DS
+// instructions attributed to THESE lines: a value that goes straight into one of the inline-asm butterflies is otherwise
+// re-created by the DAG combiner -- bitcast of a load -> load of the other type -- with the source line of that butterfly, and the
+// gate could not tell the exchange load from a table read.  It stands behind all 16 loads so that the load-store vectorizer still
+// pairs them into ds_read2_b64.)
+template <int STRIDE>
+__device__ __forceinline__ void xst16(char *p, const cf (&v)[16])
+{
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        *reinterpret_cast<f2v *>(p + j * STRIDE) = v[j]; /* LDSX:STORE (the gate keys on this line) */
+}
+template <int STRIDE>
+__device__ __forceinline__ void xld16(const char *p, cf (&v)[16])
+{
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        v[j] = *reinterpret_cast<const f2v *>(p + j * STRIDE); /* LDSX:LOAD (the gate keys on this line) */
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        asm("" : "+v"(v[j])); /* LDSX:LOAD (a load folded into its user takes this line) */
+}
+// The lane's four exchange addresses in its wave's buffer (computed once per kernel; the read bases opaque):
+//   X (16x16 transposition inside each 16-lane row g; m = lane % 16): element j is written to wx + j XROW, read from rx + 8 j
+//   Y (inverse_tail256 / inverse_dec4_tan: element mu1 of lane (k0, low) -> lane 4 mu1 + low, slot k0): wy + j XROW, ry + 8 j
+struct XAddr
+{
+    char *wx;
+    const char *rx;
+    char *wy;
+    const char *ry;
+};
+__device__ __forceinline__ XAddr xaddr_x(char *xb, int lane)
 {
     const int g = lane >> 4, m = lane & 15;
-    char *wr = xb + g * XREG + m * 8;          // + j*XROW : element (j, m)
-    const char *rd = xb + g * XREG + m * XROW; // + j*8    : element (m, j)
+    return XAddr{xb + g * XREG + m * 8, lds_opaque(xb + g * XREG + m * XROW), nullptr, nullptr};
+}
+__device__ __forceinline__ XAddr xaddr_xy(char *xb, int lane)
+{
+    const int g = lane >> 4, m = lane & 15;
+    const int k0 = 4 * g + (m >> 2), low = m & 3;
+    return XAddr{xb + g * XREG + m * 8, lds_opaque(xb + g * XREG + m * XROW), xb + low * XREG + k0 * 8,
+                 lds_opaque(xb + (lane & 3) * XREG + (lane >> 2) * XROW)};
+}
+
+// 16x16 transposition inside each 16-lane row: element (i, j) of lane (g, m) -> lane (g, j), slot (i, m)
+__device__ __forceinline__ void exchange2(cf (&r)[64], const XAddr &xa)
+{
 #pragma unroll
     for (int i = 0; i < 4; i++)
     {
+        cf t[16];
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            *reinterpret_cast<f2v *>(wr + j * XROW) = r[phys(i, j)];
-        LDS_FENCE();
+            t[j] = r[phys(i, j)];
+#if defined(IF_FIR_FFT_LDSX_PROBE) && IF_FIR_FFT_LDSX_PROBE == 1
+        // (tests/test_host.py: a deliberately mis-ordered exchange -- the second half of the stores behind the loads of the first
+        // half's partners; the gate must flag it)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            *reinterpret_cast<f2v *>(xa.wx + j * XROW) = t[j]; /* LDSX:STORE (probe) */
+        cf u[16];
+        xld16<8>(xa.rx, u);
+#pragma unroll
+        for (int j = 8; j < 16; j++)
+            *reinterpret_cast<f2v *>(xa.wx + j * XROW) = t[j]; /* LDSX:STORE (probe) */
 #pragma unroll
         for (int j = 0; j < 16; j++)
-        {
-            r[phys(i, j)] = *reinterpret_cast<const f2v *>(rd + j * 8);
-        }
-        LDS_FENCE();
+            t[j] = u[j];
+#else
+        xst16<XROW>(xa.wx, t);
+        xld16<8>(xa.rx, t);
+#endif
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            r[phys(i, j)] = t[j];
     }
 }
 
@@ -640,44 +709,23 @@ struct DevQueue
 //   X: row transposition (one round of exchange 2): element j of lane (g, k1) -> lane (g, j), slot k1; iFFT16 over k1 -> mu1
 //   twiddle conj W256^(k0 mu1);  Y: element mu1 of lane (k0, low) -> lane 4 mu1 + low, slot k0;  iFFT16 over k0 -> mu0
 // result: lane = 4 mu1 + low, slot mu0
-__device__ __forceinline__ void inverse_tail256(cf (&a)[16], cf (&c)[16], const f2v *twe, char *xb, int lane)
+__device__ __forceinline__ void inverse_tail256(cf (&a)[16], cf (&c)[16], const f2v *twe, const XAddr &xa, int lane)
 {
-    const int g = lane >> 4, m = lane & 15;
-    {
-        char *wr = xb + g * XREG + m * 8;
-        const char *rd = xb + g * XREG + m * XROW;
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
-        LDS_FENCE();
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            a[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
-        LDS_FENCE();
-    }
+    xst16<XROW>(xa.wx, a);
+    xld16<8>(xa.rx, a);
     fft16<true>(a); // over k1 -> mu1
 #pragma unroll
     for (int mu1 = 1; mu1 < 16; mu1++)
         a[mu1] = cmul_v<true>(a[mu1], twe[mu1 * 64 + lane]);
-    {
-        const int k0 = 4 * g + (m >> 2), low = m & 3;
-        char *wr = xb + low * XREG + k0 * 8;                          // + mu1*XROW : element (mu1, k0) of region `low`
-        const char *rd = xb + (lane & 3) * XREG + (lane >> 2) * XROW; // + k0*8
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
-        LDS_FENCE();
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            c[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
-        LDS_FENCE();
-    }
+    // Y: wy + mu1 XROW = element (mu1, k0) of region `low`; ry + 8 k0
+    xst16<XROW>(xa.wy, a);
+    xld16<8>(xa.ry, c);
     fft16<true>(c); // over k0 -> mu0
 }
 
 // decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
 // (4 x 16 x 16, tools/fft_model.py inverse_dec4) produces y[4m'] directly: lane = 4*mu1+mu2, slot mu0 -> y_D[64*mu0+lane]
-__device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], const f2v *twd, const f2v *twe, char *xb,
+__device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], const f2v *twd, const f2v *twe, const XAddr &xa,
                                              int lane)
 {
     cf a[16];
@@ -689,45 +737,23 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
         for (int mu2 = 1; mu2 < 4; mu2++)
             a[4 * i + mu2] = cmul_v<true>(a[4 * i + mu2], twd[(i * 4 + mu2) * 64 + lane]);
     }
-    inverse_tail256(a, c, twe, xb, lane);
+    inverse_tail256(a, c, twe, xa, lane);
 }
 
 // the same with the twiddles in (cos, tan) form on the inputs of the two 16-point transforms (round 4; tables tb = LDS_TWE,
 // tc = LDS_TWD): 4-point inverse over k2' (plain) -> X -> iFFT16 over k1, inputs carry conj(W64^mu2)^k1 -> Y -> iFFT16 over k0,
 // inputs carry conj(W1024^lane)^k0.  208 packed instructions where inverse_dec4 has 246.
-__device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16], const f2v *tb, const f2v *tc, char *xb, int lane)
+__device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16], const f2v *tb, const f2v *tc, const XAddr &xa, int lane)
 {
     cf a[16];
 #pragma unroll
     for (int i = 0; i < 4; i++)
         bfly4<true>(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3], a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
-    const int g = lane >> 4, m = lane & 15;
-    {
-        char *wr = xb + g * XREG + m * 8;
-        const char *rd = xb + g * XREG + m * XROW;
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
-        LDS_FENCE();
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            a[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
-        LDS_FENCE();
-    }
+    xst16<XROW>(xa.wx, a);
+    xld16<8>(xa.rx, a);
     fft16_tw<true, 4>(a, tb + (lane & 3)); // over k1 -> mu1
-    {
-        const int k0 = 4 * g + (m >> 2), low = m & 3;
-        char *wr = xb + low * XREG + k0 * 8;
-        const char *rd = xb + (lane & 3) * XREG + (lane >> 2) * XROW;
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            *reinterpret_cast<f2v *>(wr + j * XROW) = a[j];
-        LDS_FENCE();
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            c[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
-        LDS_FENCE();
-    }
+    xst16<XROW>(xa.wy, a);
+    xld16<8>(xa.ry, c);
     fft16_tw<true, 64>(c, tc + lane); // over k0 -> mu0
 }
 
@@ -762,37 +788,24 @@ template <int F> struct OddLds
 // (v = the output of the first pass, the plain FFT16 over the rows, of the lane whose in-lane-order index lsrc = 4 mu1 + mu2 gave
 // wr_off = (lsrc & 3) XREG + (lsrc >> 2) XROW: the kernel runs that pass on its coalesced registers and lets every lane deliver
 // the column it happens to hold)
-__device__ __forceinline__ void forward_1024_tan(cf (&v)[16], cf (&z)[16], const f2v *tb, const f2v *tc, char *xb, int lane, int wr_off)
+// (xa: the X / Y addresses of the inverse; ryi: the OPAQUE read base of Y^-1, the address formula of xa.wy)
+__device__ __forceinline__ void forward_1024_tan(cf (&v)[16], cf (&z)[16], const f2v *tb, const f2v *tc, char *xb, const XAddr &xa,
+                                                 const char *ryi, int lane, int wr_off)
 {
-    const int g = lane >> 4, m = lane & 15;
     cf y[16];
     {
-        // Y^-1: element k0 of lane 4 mu1 + mu2 -> lane (k0, mu2), slot mu1 (the addresses of inverse_tail256's Y, roles swapped)
-        char *wr = xb + wr_off;                                      // + k0*8
-        const int k0 = 4 * g + (m >> 2), low = m & 3;
-        const char *rd = xb + low * XREG + k0 * 8;                   // + mu1*XROW
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            *reinterpret_cast<f2v *>(wr + j * 8) = v[j];
-        LDS_FENCE();
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            y[j] = *reinterpret_cast<const f2v *>(rd + j * XROW);
-        LDS_FENCE();
+        // Y^-1: element k0 of lane 4 mu1 + mu2 -> lane (k0, mu2), slot mu1 (the addresses of inverse_tail256's Y, roles swapped):
+        // written to xb + wr_off + 8 k0, read from ryi + mu1 XROW
+        char *wr = xb + wr_off;
+        const int k0 = 4 * (lane >> 4) + ((lane & 15) >> 2);
+        xst16<8>(wr, v);
+        xld16<XROW>(ryi, y);
         fft16_tw<false, 16>(y, tb + k0); // over mu1 -> k1
     }
     {
         // X^-1 (the row transposition is its own inverse): element k1 of lane (g, j) -> lane (g, k1), slot j = 4 i + mu2
-        char *wr = xb + g * XREG + m * 8;
-        const char *rd = xb + g * XREG + m * XROW;
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            *reinterpret_cast<f2v *>(wr + j * XROW) = y[j];
-        LDS_FENCE();
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-            y[j] = *reinterpret_cast<const f2v *>(rd + j * 8);
-        LDS_FENCE();
+        xst16<XROW>(xa.wx, y);
+        xld16<8>(xa.rx, y);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -875,6 +888,8 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
     const f2v *ncob = reinterpret_cast<const f2v *>(smem + L::NCO);
     (void)ncob;
     char *xb = smem + L::XB + wid * L::WBUF;
+    const XAddr xa = xaddr_xy(xb, lane);
+    const char *ryi = lds_opaque(xa.wy); // Y^-1 of the forward transforms reads where the inverse's Y writes
     // x[p][row]: piece p of row r = the 64 samples F 64 r + 64 p + lane of the block, 512 contiguous bytes per load instruction (the
     // in-lane order -- sample F (64 row + lane) + p -- only in the first block of a call).  The first form of this kernel loaded
     // the F samples of a lane directly (8 bytes per lane, 24 apart): every instruction then touched all 12 lines of a row, three
@@ -981,7 +996,7 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 v[r] = x[p][r];
-            forward_1024_tan(v, z, tb, tc, xb, lane, inlane ? wr_std : wr_ph[p]);
+            forward_1024_tan(v, z, tb, tc, xb, xa, ryi, lane, inlane ? wr_std : wr_ph[p]);
 #pragma unroll
             for (int sidx = 0; sidx < 16; sidx++)
             {
@@ -1001,7 +1016,7 @@ __global__ __launch_bounds__(512, 2) void fir_odd_kernel(const f2v *__restrict__
                 load_phase(nsrd, p);
         }
         cf c[16];
-        inverse_dec4_tan(zacc, c, twe, twd, xb, lane);
+        inverse_dec4_tan(zacc, c, twe, twd, xa, lane);
         if (next_fast)
         {
 #pragma unroll
@@ -1307,6 +1322,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     const f2v *ncob = reinterpret_cast<const f2v *>(smem + LDS_NCO); // NCO: phasor of output row r of a block
     (void)ncob;
     char *xb = smem + LDS_XB + wid * XBUF;
+    const XAddr xa = DEC4 ? xaddr_xy(xb, lane) : xaddr_x(xb, lane); // the lane's exchange addresses (read bases opaque)
     (void)twd;
     (void)twe;
     // full-rate pipeline: the shared table T and this lane's three positions in it (tsw)
@@ -1461,7 +1477,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             }
         }
         FFT_STAMP(3);
-        exchange2(r, xb, lane);
+        exchange2(r, xa);
         FFT_STAMP(4);
         int64_t blk_next = blk + 1;
         if (static_map)
@@ -1547,7 +1563,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 if (wanted)
                 {
                     cf c[16];
-                    inverse_tail256(a, c, twe, xb, lane);
+                    inverse_tail256(a, c, twe, xa, lane);
                     // this lane's channel: its buffer (pointer table in LDS) and the call-constant mix-down phase
                     // exp(-j 2 pi s (abs0 + n0) / 16) = W16^(s rot_e) (table entries 16..31: the 16th roots of unity)
                     float2 *po = reinterpret_cast<float2 *const *>(smem + LDS_QPTR)[4 * b + cs];
@@ -1659,13 +1675,13 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                     for (int q = 0; q < 4; q++)
                         z[4 * i + q] = r[phys(i, q)];
-                inverse_dec4(z, ce, twd, twe, xb, lane);
+                inverse_dec4(z, ce, twd, twe, xa, lane);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int q = 0; q < 4; q++)
                         z[4 * i + q] = r[phys(i, q + 4)];
-                inverse_dec4(z, co, twd, twe, xb, lane);
+                inverse_dec4(z, co, twd, twe, xa, lane);
             }
             if constexpr (NCO)
             {
@@ -1798,7 +1814,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     }
                 }
                 cf c[16];
-                inverse_tail256(a, c, twe, xb, lane);
+                inverse_tail256(a, c, twe, xa, lane);
                 if (last && next_fast)
                 {
 #pragma unroll
@@ -1942,7 +1958,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 if (wanted)
                 {
                     cf c[16];
-                    inverse_tail256(a, c, twe, xb, lane);
+                    inverse_tail256(a, c, twe, xa, lane);
                     // lane = 4 mu1 + 2 ch + mu2, slot mu0 -> y_s[32 mu0 + 2 mu1 + mu2], s = 2 (2 b + ch) + par.  Mix-down: the call
                     // constant W16^(s rot_e) (16th roots: table entries 16..31) times (-1)^(s m), m = obase + 32 (..) + 2 mu1 + mu2
                     // with obase even: the sign is (-1)^(s mu2)
@@ -2048,7 +2064,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     }
                 }
                 cf c[16];
-                inverse_tail256(a, c, twe, xb, lane);
+                inverse_tail256(a, c, twe, xa, lane);
                 if (last && next_fast)
                 {
 #pragma unroll
@@ -2141,7 +2157,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     }
                 }
                 cf c[16];
-                inverse_tail256(a, c, twe, xb, lane);
+                inverse_tail256(a, c, twe, xa, lane);
                 if (last && next_fast)
                 {
 #pragma unroll
@@ -2261,9 +2277,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 }
                 cf c[16];
                 if constexpr (TAN)
-                    inverse_dec4_tan(z, c, twe, twd, xb, lane);
+                    inverse_dec4_tan(z, c, twe, twd, xa, lane);
                 else
-                    inverse_dec4(z, c, twd, twe, xb, lane);
+                    inverse_dec4(z, c, twd, twe, xa, lane);
                 if (last && next_fast)
                 {
 #pragma unroll
@@ -2342,7 +2358,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     }
                 }
                 cf c[16];
-                inverse_dec4_tan(z, c, twe, twd, xb, lane);
+                inverse_dec4_tan(z, c, twe, twd, xa, lane);
                 if (last && next_fast)
                 {
 #pragma unroll
@@ -2436,9 +2452,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             FFT_STAMP(5);
             cf c[16];
             if constexpr (TAN)
-                inverse_dec4_tan(z, c, twe, twd, xb, lane);
+                inverse_dec4_tan(z, c, twe, twd, xa, lane);
             else
-                inverse_dec4(z, c, twd, twe, xb, lane);
+                inverse_dec4(z, c, twd, twe, xa, lane);
             FFT_STAMP(6);
             if (next_fast)
             {
@@ -2511,7 +2527,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 for (int j = 0; j < 16; j++)
                     r[phys(i, j)] = t[j];
                 }
-            exchange2(r, xb, lane);
+            exchange2(r, xa);
 #pragma unroll
             for (int i = 0; i < 4; i++)
             {

@@ -464,6 +464,32 @@ def test_wide_store_hazard_scanner_flags_the_round_3_form_and_passes_the_build()
     assert not tool.scan_text(st + "\ts_nop 1\n\tv_pk_mul_f32 v[10:11], v[2:3], v[4:5]\n")
     assert not tool.scan_text(st + "\tv_pk_add_f32 v[14:15], v[2:3], v[4:5]\n\tv_pk_add_f32 v[8:9], v[2:3], v[4:5]\n")
     assert tool.scan_text("\tglobal_store_dwordx4 v[2:3], v[10:13], off\n\tv_permlane32_swap_b32_e32 v1, v11\n")
+    # round 5: the scan goes on behind a conditional branch -- on the fall-through path (the branch is one wait state) and
+    # at its target (a loop's back edge: the store at the end of the loop body, the VALU write at its head)
+    assert tool.scan_text(st + "\ts_cbranch_vccnz .LBB0_9\n\tv_mov_b32_e32 v11, 0\n.LBB0_9:\n\ts_endpgm\n")
+    assert not tool.scan_text(st + "\ts_cbranch_vccnz .LBB0_9\n\ts_nop 0\n\tv_mov_b32_e32 v11, 0\n.LBB0_9:\n\ts_endpgm\n")
+    loop = ".LBB0_1:\n\tv_pk_add_f32 v[12:13], v[2:3], v[4:5]\n\ts_add_u32 s4, s4, 1\n\ts_cmp_lt_u32 s4, s5\n" + st
+    assert tool.scan_text(loop + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")               # back edge: 1 wait state, then the write
+    assert not tool.scan_text(loop + "\ts_nop 0\n\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    assert tool.scan_text(st + "\ts_branch .LBB0_7\n\ts_nop 4\n.LBB0_7:\n\tv_mov_b32_e32 v13, 1.0\n")       # unconditional: the target
+    assert tool.scan_text(st + "\ts_cbranch_execz .Lnowhere\n\ts_nop 4\n")                                    # unresolvable target
+    # the same through the addresses of a disassembly
+    dis = ("0000000000001000 <kern>:\n\tv_pk_add_f32 v[12:13], v[2:3], v[4:5]  // 000000001000: D3B2000C\n"
+           "\tbuffer_store_dwordx4 v[10:13], v40, s[36:39], 0 offen  // 000000001008: E07C1000\n"
+           "\ts_cbranch_scc1 65532  // 000000001010: BF85FFFC <kern+0x0>\n\ts_endpgm  // 000000001014: BF810000\n")
+    assert tool.scan_text(dis)
+    # a bundle without device code is an error, not "0 wide stores, 0 violations"
+    import isa_tools
+    with tempfile.TemporaryDirectory() as td:
+        hostonly = os.path.join(td, "host.o")
+        open(os.path.join(td, "h.c"), "w").write("int f(void) { return 1; }\n")
+        subprocess.check_call(["gcc", "-c", os.path.join(td, "h.c"), "-o", hostonly])
+        try:
+            tool.disassemble(hostonly)
+            raise AssertionError("a host-only object must not disassemble to an empty text")
+        except (isa_tools.NoDeviceCode, subprocess.CalledProcessError):
+            pass
+        assert tool.main([hostonly]) == 1
     csrc = os.path.join(ROOT, "qo-100-tools_amd", "csrc")
     with tempfile.TemporaryDirectory() as td:
         for probe, expect_bad in ((1, True), (2, False)):
@@ -482,6 +508,87 @@ def test_wide_store_hazard_scanner_flags_the_round_3_form_and_passes_the_build()
         text = tool.disassemble(path)
         assert tool.count_wide_stores(text) > 0 or o == "if_fir_fft_odd.o", o      # (the odd-decimation kernel stores 8 bytes per lane)
         assert not tool.scan_text(text, o), o
+
+
+def _exchange_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lds_exchange", os.path.join(ROOT, "tools", "check_lds_exchange.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_lds_exchange_order_gate_flags_a_reordered_probe_and_passes_the_build():
+    """the lane exchanges of the overlap-save kernels (16 stores per lane into the wave's LDS buffer, 16 loads, the next
+    exchange's stores) are correct only while the instruction stream keeps the phases apart; for the compiler they are plain
+    loads and stores of one thread, and for most pairs an alias-freedom proof exists.  The source now routes every exchange load
+    through an opaque base address (no proof possible: the language pins the order), and the build walks every kernel's
+    line-annotated disassembly (tools/check_lds_exchange.py).  Here: synthetic streams, a deliberately mis-ordered probe compiled from
+    the kernel source (IF_FIR_FFT_LDSX_PROBE=1: the last store of a phase behind its first load) must be flagged, the correct
+    one and every unit of the build must pass, and the line tables the classification needs must not change the code."""
+    import subprocess
+    import tempfile
+    tool = _exchange_tool()
+    csrc = os.path.join(ROOT, "qo-100-tools_amd", "csrc")
+    src = os.path.join(csrc, "if_fir_fft.hip")
+    tags = tool.tagged_lines(src)
+    lw = [k for k, v in tags.items() if v == "W"][0]
+    lr = [k for k, v in tags.items() if v == "R"][0]
+    assert len(tags) >= 12     # the two helpers and every call site
+
+    def stream(*parts):
+        out = ["0000000000001000 <_ZN6if_fir14fir_fft_kernelILi4EEEvv>:"]
+        for kind, n in parts:
+            if kind == "W":
+                out.append("; %s:%d" % (src, lw))
+                out += ["\tds_write_b64 v1, v[2:3] offset:%d  // 000000001000: 0" % (136 * k) for k in range(n)]
+            elif kind == "R":
+                out.append("; %s:%d" % (src, lr))
+                out += ["\tds_read2_b64 v[4:7], v9 offset0:%d offset1:%d  // 000000001000: 0" % (2 * k, 2 * k + 1) for k in range(n // 2)]
+                out += ["\tds_read_b64 v[4:5], v9  // 000000001000: 0"] * (n % 2)
+            elif kind == "T":    # table reads: another source line, ignored wherever they stand
+                out.append("; %s:%d" % (src, 1))
+                out += ["\tds_read2_b64 v[4:7], v8 offset0:4 offset1:8  // 000000001000: 0"] * n
+            else:                # a DS instruction without a source line
+                out.append("; %s:0" % src)
+                out += ["\tds_read_b64 v[4:5], v9  // 000000001000: 0"]
+        return "\n".join(out) + "\n"
+
+    base = os.path.basename(src)
+    ok = lambda *parts: tool.scan_text(stream(*parts), tags, base)[0]
+    assert not ok(("W", 16), ("T", 3), ("R", 16), ("W", 16), ("R", 16))
+    assert not ok(("W", 8), ("T", 2), ("W", 8), ("R", 6), ("T", 1), ("R", 10))
+    assert ok(("W", 15), ("R", 2), ("W", 1), ("R", 14))                 # a load ahead of the phase's last store
+    assert ok(("W", 16), ("R", 14), ("W", 16), ("R", 18))               # the next exchange's stores ahead of the last loads
+    assert ok(("W", 16), ("W", 16), ("R", 16), ("R", 16))               # two exchanges interleaved
+    assert ok(("W", 16), ("R", 16), ("W", 16))                          # ends inside an exchange
+    assert ok(("T", 4))                                                 # a kernel of the family without any classified access
+    assert ok(("W", 16), ("X", 1), ("R", 16))                           # a DS instruction without a source line
+    flags = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
+             "-I" + csrc, "-DIF_FIR_FFT_ROWS=4", "-DIF_FIR_FFT_HAZARD_PROBE=2"]
+    with tempfile.TemporaryDirectory() as td:
+        for probe, expect_bad in ((1, True), (0, False)):
+            out = os.path.join(td, "probe%d.o" % probe)
+            subprocess.check_call(flags + ["-gline-tables-only", "-DIF_FIR_FFT_LDSX_PROBE=%d" % probe, "-c", src, "-o", out], stderr=subprocess.DEVNULL)
+            bad, units = tool.scan_text(tool.isa_tools.disassemble(out, lines=True), tags, base, "probe%d" % probe)
+            assert bool(bad) == expect_bad, (probe, bad[:3])
+            assert sum(units.values()) >= 8, units
+        # line tables do not change the generated code: the same unit without them disassembles to the same instructions
+        plain = os.path.join(td, "plain.o")
+        subprocess.check_call(flags + ["-DIF_FIR_FFT_LDSX_PROBE=0", "-c", src, "-o", plain], stderr=subprocess.DEVNULL)
+        strip = lambda t: [ln.split("//")[0].rstrip() for ln in t.splitlines() if ln.startswith("\t")]
+        a = strip(tool.isa_tools.disassemble(plain))
+        b = strip(tool.isa_tools.disassemble(os.path.join(td, "probe0.o")))
+        assert a == b and len(a) > 3000
+    for o in ["if_fir_fft_r%d.o" % r for r in (4, 8, 16, 32, 48)] + ["if_fir_fft_odd.o"]:
+        path = os.path.join(csrc, o)
+        assert os.path.exists(path), "build() first: %s" % o
+        bad, units = tool.scan_text(tool.isa_tools.disassemble(path, lines=True), tags, base, o)
+        fam = {k: n for k, n in units.items() if any(f in k for f in tool.FAMILY) and not k.endswith(".kd")}
+        assert not bad, (o, bad[:3])
+        assert len(fam) >= 16 and min(fam.values()) >= 4, (o, len(fam))    # every kernel: exchange 2 (four rounds) at least
+    # the fence macro of round 4 is gone: the order no longer depends on a switch
+    assert "LDS_FENCE" not in open(src).read()
 
 
 def test_bench_line_contract_on_the_committed_run():

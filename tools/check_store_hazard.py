@@ -9,16 +9,22 @@ the scalar offset 0).  Nothing in the language stops an edit or a compiler from 
 is scanned: every store of 3 or 4 dwords, of any encoding, must be followed by at least WAIT_STATES wait states before a
 VALU instruction writes one of its data registers.  A wait state = one instruction issued (`s_nop N` counts N + 1).
 
+Round 5: the scan no longer stops at a conditional branch -- the fall-through path goes on (the branch counts as one
+wait state) AND the branch target is scanned with the same count (a loop's back edge: the stores of the kernels sit at the end
+of the per-block loop, the first VALU writes of the next iteration at its head); an unconditional branch follows its target.  An
+object that yields no device disassembly, or a device object without a single wide store where the caller expects some
+(--expect-stores), is an error instead of "0 violations".
+
 Exit code 1 and one line per violation; used by csrc/Makefile on each overlap-save unit and by tests/test_host.py.
 """
 import os
 import re
-import subprocess
 import sys
-import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import isa_tools  # noqa: E402
 
 WAIT_STATES = 2
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 _STORE = re.compile(r"^\s*(buffer_store_(?:dwordx[34]|format_xyzw?)|global_store_dwordx[34]|flat_store_dwordx[34]|"
                     r"scratch_store_dwordx[34])\s+(.*)$")
@@ -34,15 +40,9 @@ def _regs(tok):
     return int(m.group(1)), int(m.group(2))
 
 
-def _instr(line):
-    """mnemonic and operand string of a disassembly / assembly line, or None (labels, directives, comments)."""
-    line = line.split("//")[0].split(";")[0].strip()
-    if not line or line.endswith(":") or line.startswith("."):
-        return None
-    m = re.match(r"^(?:[0-9a-f]+:\s+)?([a-z][a-z0-9_]*)\s*(.*)$", line)
-    if not m:
-        return None
-    return m.group(1), m.group(2)
+_instr = isa_tools.instr
+_ADDR = re.compile(r"//\s*([0-9A-Fa-f]+):")
+_TARGET = re.compile(r"<[^>+]+\+0x([0-9A-Fa-f]+)>|<([^>+]+)>\s*$")
 
 
 def _store_data(mn, ops):
@@ -70,41 +70,84 @@ def _valu_writes(mn, ops):
     return out
 
 
+def _branch_target(line, labels, addr_index, sym_addr):
+    """instruction index a branch goes to: an assembly label operand, or the `<symbol+0xoff>` of a disassembly line"""
+    d = _instr(line)
+    tok = d[1].split(",")[-1].strip().split()[0] if d and d[1].strip() else ""
+    if tok in labels:
+        return labels[tok]
+    m = re.search(r"<([^>+]+)\+0x([0-9A-Fa-f]+)>", line)
+    if m and m.group(1) in sym_addr:
+        return addr_index.get(sym_addr[m.group(1)] + int(m.group(2), 16))
+    m = re.search(r"<([^>+]+)>\s*$", line)
+    if m and m.group(1) in sym_addr:
+        return addr_index.get(sym_addr[m.group(1)])
+    return None
+
+
 def scan_text(text, where=""):
     """list of violation strings"""
     lines = text.splitlines()
-    ins = []
+    ins = []          # (line number, mnemonic, operands, raw line)
+    labels = {}       # assembly label -> index of the next instruction
+    addr_index = {}   # disassembly address -> instruction index
+    sym_addr = {}     # disassembly symbol -> address
     for i, ln in enumerate(lines):
+        lab = isa_tools.label(ln)
+        if lab is not None:
+            labels[lab] = len(ins)
+            m = re.match(r"^([0-9a-fA-F]+)\s+<", ln.strip())
+            if m:
+                sym_addr[lab] = int(m.group(1), 16)
+            continue
         d = _instr(ln)
         if d:
-            ins.append((i + 1, d[0], d[1]))
-    bad = []
-    for k, (lineno, mn, ops) in enumerate(ins):
+            m = _ADDR.search(ln)
+            if m:
+                addr_index[int(m.group(1), 16)] = len(ins)
+            ins.append((i + 1, d[0], d[1], ln))
+    bad = set()
+    for k, (lineno, mn, ops, _) in enumerate(ins):
         if not _STORE.match(mn + " " + ops):
             continue
         data = _store_data(mn, ops)
         if not data:
             continue
-        ws = 0
-        j = k + 1
-        while j < len(ins) and ws < WAIT_STATES:
-            _, m2, o2 = ins[j]
-            if m2 in ("s_endpgm", "s_branch", "s_setpc_b64") or m2.startswith("s_cbranch"):
-                break
-            for (a, b) in _valu_writes(m2, o2):
-                if a <= data[1] and b >= data[0]:
-                    bad.append("%s:%d: `%s %s` overwrites data registers v[%d:%d] of the %d-dword store at line %d after %d wait "
-                               "state(s) (need %d)" % (where, ins[j][0], m2, o2.strip(), data[0], data[1], data[1] - data[0] + 1,
-                                                       lineno, ws, WAIT_STATES))
-            if m2 == "s_nop":
-                try:
-                    ws += int(o2.strip(), 0) + 1
-                except ValueError:
+        # walk every path behind the store until WAIT_STATES wait states have passed
+        work, seen = [(k + 1, 0)], set()
+        while work:
+            j, ws = work.pop()
+            while j < len(ins) and ws < WAIT_STATES and (j, ws) not in seen:
+                seen.add((j, ws))
+                l2, m2, o2, raw = ins[j]
+                if m2 in ("s_endpgm", "s_setpc_b64", "s_swappc_b64"):
+                    break
+                if m2 == "s_branch" or m2.startswith("s_cbranch"):
+                    t = _branch_target(raw, labels, addr_index, sym_addr)
+                    if t is None:
+                        bad.add("%s:%d: the %d-dword store at line %d is followed within %d wait state(s) by `%s %s` whose target the "
+                                "scanner cannot resolve" % (where, l2, data[1] - data[0] + 1, lineno, ws, m2, o2.strip()))
+                    else:
+                        work.append((t, ws + 1))
+                    if m2 == "s_branch":
+                        break
                     ws += 1
-            else:
-                ws += 1
-            j += 1
-    return bad
+                    j += 1
+                    continue
+                for (a, b) in _valu_writes(m2, o2):
+                    if a <= data[1] and b >= data[0]:
+                        bad.add("%s:%d: `%s %s` overwrites data registers v[%d:%d] of the %d-dword store at line %d after %d wait "
+                                "state(s) (need %d)" % (where, l2, m2, o2.strip(), data[0], data[1], data[1] - data[0] + 1,
+                                                        lineno, ws, WAIT_STATES))
+                if m2 == "s_nop":
+                    try:
+                        ws += int(o2.strip(), 0) + 1
+                    except ValueError:
+                        ws += 1
+                else:
+                    ws += 1
+                j += 1
+    return sorted(bad)
 
 
 def count_wide_stores(text):
@@ -112,25 +155,31 @@ def count_wide_stores(text):
 
 
 def disassemble(path):
-    """device disassembly of a hipcc object (offload bundle), or the text of a .s / .dis file"""
-    if path.endswith((".s", ".dis", ".txt")):
-        return open(path).read()
-    with tempfile.TemporaryDirectory() as td:
-        local = os.path.join(td, os.path.basename(path))
-        os.symlink(os.path.abspath(path), local)
-        subprocess.check_call([OBJDUMP, "--offloading", local], cwd=td, stdout=subprocess.DEVNULL)
-        cos = [f for f in os.listdir(td) if "amdgcn" in f]
-        if not cos:
-            return ""   # a host-only object
-        return "".join(subprocess.check_output([OBJDUMP, "-d", os.path.join(td, f)], text=True) for f in cos)
+    """device disassembly of a hipcc object (offload bundle), or the text of a .s / .dis file; a bundle without device code raises"""
+    return isa_tools.disassemble(path)
 
 
 def main(argv):
+    expect = False
+    if argv and argv[0] == "--expect-stores":
+        expect, argv = True, argv[1:]
     rc = 0
     for p in argv:
-        text = disassemble(p)
+        try:
+            text = disassemble(p)
+        except isa_tools.NoDeviceCode as e:
+            print("%s: %s" % (os.path.basename(p), e))
+            rc = 1
+            continue
         bad = scan_text(text, os.path.basename(p))
-        print("%s: %d wide stores, %d hazard violation(s)" % (os.path.basename(p), count_wide_stores(text), len(bad)))
+        n = count_wide_stores(text)
+        print("%s: %d wide stores, %d hazard violation(s)" % (os.path.basename(p), n, len(bad)))
+        if not any(_instr(ln) for ln in text.splitlines()):
+            print("  %s: the disassembly holds no instruction" % os.path.basename(p))
+            rc = 1
+        if expect and n == 0:
+            print("  %s: no wide store found where the build expects some (--expect-stores): is the disassembly what it should be?" % os.path.basename(p))
+            rc = 1
         for b in bad:
             print("  " + b)
             rc = 1
