@@ -303,6 +303,19 @@ static_assert(LDS_XB == FFT_TABLE_FLOATS * 4, "table image size");
 //   LDS_TW1: [0, 6 KB) forward pass 3, first stage, as above; [8 KB, 32 KB) T: three arrays of 1024 entries (fft16_tw_T, tsw)
 //   LDS_TW2: forward pass 2 as above;  LDS_TWD: inverse pass 2 [e*16 + lane%16], b = W256^(lane%16);  LDS_HP: H / 4096
 constexpr int LDS_TT = LDS_TW1 + 8192;
+// Phasor tables (round 5): every (cos, tan) image leaves bytes [6 KB, 8 KB) of the LDS_TW1 slot free; they hold P1[k] = exp(j 2 pi k /
+// 2^7) and P2[k] = exp(j 2 pi k / 2^14), k = 0..127 (host, fft_phasor_tables), and a 32-bit phase becomes a phasor with two table
+// reads, a second-order polynomial for its low 18 bits (angle < 3.9e-4 rad: the cubic term is 1e-11) and two complex multiplies --
+// about 12 instructions where the two sincospif of nco_phasor are about 80, once per block and lane in every kernel with an NCO and
+// once per channel group in the filter bank's general forms.
+constexpr int LDS_PH = LDS_TW1 + 6144;
+__device__ __forceinline__ cf lds_phasor(const f2v *pht, uint32_t ph) // exp(+j 2 pi ph / 2^32)
+{
+    const cf a = pht[ph >> 25], b = pht[128u + ((ph >> 18) & 127u)];
+    const float th = (float)(ph & 0x3ffffu) * 1.4629180792671596e-9f; // 2 pi / 2^32
+    const cf lo = {__builtin_fmaf(-0.5f * th, th, 1.0f), th};
+    return cmul_v<false>(cmul_v<false>(a, b), lo);
+}
 // Row loads: the first and last EDGE rows of a block keep the default cache policy, the rows in between are `nt`.  EDGE = the block
 // overlap (the neighbouring block finds the shared rows in L2, round 2).  Round 4 swept larger values (IF_FIR_FFT_EDGE_MIN_FULL /
 // _DEC for the full-rate pipeline / the decimating tails, profiles/r04_edge_rows.txt): 2^28-sample launches lose 2-3 % with more
@@ -569,6 +582,28 @@ __device__ __forceinline__ void buf_store(srd_t rsrc, unsigned voff, unsigned so
     __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, IF_FIR_FFT_STORE_AUX);
 }
 
+// The filter bank's tails store per lane: every lane writes the NOUT outputs it holds to ITS channel's buffer, element k at
+// pl + k STEP.  Round 4 tested `index < M` in front of every store -- a branch, an exec mask and a 64-bit address per output.  Here a
+// block all of whose outputs exist (wave-uniform; every block of a call but possibly the last) stores through ONE per-lane base
+// address with immediate offsets and no test; the last block keeps the per-output test.
+template <int NOUT, int STEP, typename F>
+__device__ __forceinline__ void store_lane_rows(cf *pl, bool full, int64_t idx0, int64_t M, F &&value)
+{
+    if (full)
+    {
+#pragma unroll
+        for (int k = 0; k < NOUT; k++)
+            __builtin_nontemporal_store(value(k), pl + k * STEP);
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < NOUT; k++)
+            if (idx0 + k * STEP < M)
+                __builtin_nontemporal_store(value(k), pl + k * STEP);
+    }
+}
+
 // Decimations D = 4 * sub (8, 12, ..., 64) behind the decimate-by-4 tail, D = 2 * sub (6, 10, ..., 62) behind the decimate-by-2 one: the tail
 // runs at the fs/F rate and every sub-th of its outputs is a real output.  The block grid starts at a kept output (the launcher
 // shifts it by the call's decimation phase), so tail output number i (counted over the whole call) is kept when i is a
@@ -757,6 +792,47 @@ __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16],
     fft16_tw<true, 64>(c, tc + lane); // over k0 -> mu0
 }
 
+
+// ---- filter bank, channels at their own centres: one folded value of a channel (round 5) ------------------------
+//     z = sum_n d[n] w[n] g[n GS],  n = 0 .. N - 1,  w[0] = 1, w[n] = tw[n - 1] wave-uniform (the channel's W4096^(n B), SGPRs),
+// g = the lane's gathered table entries (LDS).  Round 4 wrote this as one chain `z = cmac(z, cmul_s(d, w), g[..])`, and the compiler
+// produced exactly that: every table read directly in front of its use (a full LDS round trip exposed per term, `s_waitcnt
+// lgkmcnt(0)` behind each ds_read), one dependent chain of 2 N packed FMAs, and the twiddles' scalar loads in the middle (scalar
+// loads return out of order, so each of them drains the LDS reads in flight): SQ_WAIT_ANY 46-54 % of the wave cycles
+// (profiles/r04_pmc_filter_bank.txt).  Here the N gathers are requested first, the N - 1 products d w -- which need no table -- are
+// formed while they fly, and the multiply-accumulates run as NA interleaved partial sums.
+// In batches of NB terms (registers: the next batch's gathers are hoisted above this batch's arithmetic by the scheduler, so
+// two batches of table entries are live at a time): per batch the NB gathers are requested first, the products d w -- which need
+// no table -- are formed while they fly, and the multiply-accumulates run as NA interleaved partial sums.
+template <int N, int GS, int NA, int NB>
+__device__ __forceinline__ cf gather_mac(const cf (&d)[N], const cf (&tw)[N - 1], const f2v *g)
+{
+    static_assert(N % NB == 0 && NB % NA == 0, "whole batches, whole rounds of the partial sums");
+    cf acc[NA];
+#pragma unroll
+    for (int b0 = 0; b0 < N; b0 += NB)
+    {
+        cf gq[NB], q[NB];
+#pragma unroll
+        for (int n = 0; n < NB; n++)
+            gq[n] = g[(b0 + n) * GS];
+        // (nothing crosses this point in the machine scheduler: left to itself it sinks every gather down to its use -- it
+        // minimises live registers -- and the wave waits a full LDS round trip per term)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NB; n++)
+            q[n] = (b0 + n == 0) ? d[0] : cmul_s<false>(d[b0 + n], tw[b0 + n - 1]);
+#pragma unroll
+        for (int n = 0; n < NB; n++)
+            acc[n % NA] = (b0 + n < NA) ? cmul_v<false>(q[n], gq[n]) : cmac_v(acc[n % NA], q[n], gq[n]);
+    }
+#pragma unroll
+    for (int k = NA / 2; k >= 1; k /= 2)
+#pragma unroll
+        for (int m = 0; m < k; m++)
+            acc[m] = acc[m] + acc[m + k];
+    return acc[0];
+}
 
 #ifdef IF_FIR_FFT_ODD // ================= odd decimations 3, 9, 15, ..., 63: their own compilation unit =================
 // Round 4: 4096 has no odd factor to fold by, so odd decimations ran the full-rate pipeline with a selecting store
@@ -1321,6 +1397,17 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
     (void)twf;
     const f2v *ncob = reinterpret_cast<const f2v *>(smem + LDS_NCO); // NCO: phasor of output row r of a block
     (void)ncob;
+    const f2v *pht = reinterpret_cast<const f2v *>(smem + LDS_PH);   // phasor tables (the (cos, tan) images: lds_phasor)
+    (void)pht;
+    auto phasor = [&](uint32_t ph) -> float2 { // exp(+j 2 pi ph / 2^32): from the tables where the image has them
+        if constexpr (TAN || TANF)
+        {
+            const cf w = lds_phasor(pht, ph);
+            return make_float2(w.x, w.y);
+        }
+        else
+            return nco_phasor(ph);
+    };
     char *xb = smem + LDS_XB + wid * XBUF;
     const XAddr xa = DEC4 ? xaddr_xy(xb, lane) : xaddr_x(xb, lane); // the lane's exchange addresses (read bases opaque)
     (void)twd;
@@ -1506,7 +1593,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
         // parked in a per-wave LDS word until the tails need it (the 16-slot tail has neither SGPRs nor VGPRs to spare)
         if constexpr (NCO && (CHAN == 16 || CHAN == 9))
         {
-            const float2 pb = nco_phasor(nco_phi0 + nco_delta * (uint32_t)obase);
+            const float2 pb = phasor(nco_phi0 + nco_delta * (uint32_t)obase);
             if (lane == 0)
                 *reinterpret_cast<cf *>(smem + LDS_QNCO + wid * 8) = (cf){pb.x, pb.y};
         }
@@ -1572,22 +1659,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         wl = cmul_v<false>(cmul_v<false>(wl, *reinterpret_cast<const cf *>(smem + LDS_QNCO + wid * 8)), ncob[32 + mu1]);
                     const int64_t o0 = obase + mu1;
                     if (po != nullptr && !(diag & 2))
-                    {
-#pragma unroll
-                        for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                        {
-                            const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
-                            if (idx < M)
-                            {
-                                cf v;
-                                if constexpr (NCO)
-                                    v = cmul_v<false>(c[mu0], cmul_v<false>(wl, ncob[mu0 - MU0_FIRST]));
-                                else
-                                    v = cmul_v<false>(c[mu0], wl);
-                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
-                            }
-                        }
-                    }
+                        store_lane_rows<16 - MU0_FIRST, 16>(reinterpret_cast<cf *>(po) + o0, obase + LOUT <= M, o0, M, [&](int k) {
+                            if constexpr (NCO)
+                                return cmul_v<false>(c[MU0_FIRST + k], cmul_v<false>(wl, ncob[k]));
+                            else
+                                return cmul_v<false>(c[MU0_FIRST + k], wl);
+                        });
                 }
                 if (b >= EARLY_B && next_fast)
                 {
@@ -1659,9 +1736,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             cf a_lane = {1.0f, 0.0f}, a_odd = {1.0f, 0.0f};
             if constexpr (NCO)
             {
-                const float2 pa = nco_phasor(nco_phi0 + nco_delta * ((uint32_t)obase + 2u * (uint32_t)lane));
+                const float2 pa = phasor(nco_phi0 + nco_delta * ((uint32_t)obase + 2u * (uint32_t)lane));
                 a_lane = (cf){pa.x, pa.y};
-                const float2 ph = nco_phasor(nco_delta);
+                const float2 ph = phasor(nco_delta);
                 const cf odd = {__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ph.x))),
                                 __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ph.y)))};
                 a_odd = cmul_s<false>(a_lane, odd);
@@ -1778,40 +1855,44 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             {
                 const bool last = cq + 4 >= nch; // the inputs of pass 3 die with the last four channels: refill with the next block
                 cf a[16];
+                // (round 5: channel by channel, its 15 twiddles loaded once and in SGPRs before its first table gather; per group the
+                // 16 gathers fly under the 15 products t[n2] W4096^(n2 B): gather_mac)
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int ch = 0; ch < 4; ch++)
+                {
+                    if (cq + ch >= nch) // fewer than four: empty quarters
+                    {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            a[4 * i + ch] = (cf){0.f, 0.f};
+                        continue;
+                    }
+                    const int cb = (int)chan.bin[cq + ch], b = cb & 255; // wave-uniform (the slot s = cb >> 8 is absorbed: see above)
+                    cf tw[15];
+#pragma unroll
+                    for (int n2 = 1; n2 < 16; n2++)
+                        tw[n2 - 1] = (cf){chan.tw[cq + ch][2 * (n2 - 1)], chan.tw[cq + ch][2 * (n2 - 1) + 1]}; // W4096^(n2 B)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        const int ik = (i - b) & 3;                            // table group of kappa (kappa % 4)
+                        const int d = lq - (b >> 2) - ((i < (b & 3)) ? 1 : 0); // (k_low - b) >> 2, negative: a borrow from k2
+                        const int lk = d & 63;
+                        const int lane_k = ((lk & 3) << 4) | (lk >> 2);        // the lane that holds kappa in group ik
+                        cf t[16];
+#pragma unroll
+                        for (int n2 = 0; n2 < 16; n2++)
+                            t[n2] = r[phys(i, n2)];
+                        a[4 * i + ch] = gather_mac<16, 64, 2, 4>(t, tw, hp + (ik * 16) * 64 + lane_k);
+                    }
+                }
+                if (last && next_fast)
                 {
 #pragma unroll
-                    for (int ch = 0; ch < 4; ch++)
-                    {
-                        if (cq + ch >= nch) // fewer than four: empty quarters
-                        {
-                            a[4 * i + ch] = (cf){0.f, 0.f};
-                            continue;
-                        }
-                        const int cb = (int)chan.bin[cq + ch], b = cb & 255, s = cb >> 8; // wave-uniform
-                        const int ik = (i - b) & 3;                                      // table group of kappa (kappa % 4)
-                        const int d = lq - (b >> 2) - ((i < (b & 3)) ? 1 : 0);           // (k_low - b) >> 2, negative: a borrow from k2
-                        const int lk = d & 63;
-                        const int lane_k = ((lk & 3) << 4) | (lk >> 2);                  // the lane that holds kappa in group ik
-                        const int sp = (s + (d < 0 ? 1 : 0)) & 15;
-                        const f2v *g = hp + (ik * 16) * 64 + lane_k; // (+ n2 * 64 entries)
-                        (void)sp; // (s' = s + cy is absorbed: see below)
-                        cf z = cmul_v<false>(r[phys(i, 0)], g[0]);
-#pragma unroll
-                        for (int n2 = 1; n2 < 16; n2++)
-                        {
-                            const cf tw = {chan.tw[cq + ch][2 * (n2 - 1)], chan.tw[cq + ch][2 * (n2 - 1) + 1]}; // W4096^(n2 B)
-                            z = cmac_v(z, cmul_s<false>(r[phys(i, n2)], tw), g[n2 * 64]);
-                        }
-                        a[4 * i + ch] = z;
-                    }
-                    if (last && i < EARLY_GROUPS && next_fast)
-                    {
+                    for (int i = 0; i < EARLY_GROUPS; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
                             load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
-                    }
                 }
                 cf c[16];
                 inverse_tail256(a, c, twe, xa, lane);
@@ -1831,7 +1912,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 float2 *po = cs == 0 ? chan.out[cq] : cs == 1 ? chan.out[c1] : cs == 2 ? chan.out[c2] : chan.out[c3];
                 const uint32_t pw = cs == 0 ? chan.pword[cq] : cs == 1 ? chan.pword[c1] : cs == 2 ? chan.pword[c2] : chan.pword[c3];
                 const int64_t o0 = obase + mu1;
-                const float2 pa = nco_phasor(0u - pw * (chan.abs0n0 + 16u * (uint32_t)o0));
+                const float2 pa = phasor(0u - pw * (chan.abs0n0 + 16u * (uint32_t)o0));
                 const cf wl = {pa.x, pa.y};
                 const f2v *rowp = rowt + cl * 16;
                 // decimation 32, 48, 64 (16 x sub): every sub-th output of this tail is a real output (KeepEvery, as behind the
@@ -1839,16 +1920,29 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 if (chan.sub == 1u) // (wave-uniform: the plain decimation keeps its plain store loop -- the thinning costs it 5 %)
                 {
                     if (cq + cs < nch && !(diag & 2))
+                        store_lane_rows<16 - MU0_FIRST, 16>(reinterpret_cast<cf *>(po) + o0, obase + LOUT <= M, o0, M, [&](int k) {
+                            return cmul_v<false>(c[MU0_FIRST + k], cmul_v<false>(wl, rowp[k]));
+                        });
+                }
+                else if ((chan.sub & (chan.sub - 1u)) == 0u && chan.sub <= 16u)
+                {
+                    // decimation 32, 64 (sub = 2, 4 divides the 16 outputs of a row): a lane keeps all of its outputs or none, and the
+                    // kept ones are 16 / sub apart -- the plain store loop with another step (round 5)
+                    KeepEvery ke;
+                    ke.init(blk, (unsigned)LOUT, chan.sub);
+                    const int64_t kept0 = ke.index((unsigned)mu1); // of the lane's first output, or -1
+                    if (cq + cs < nch && !(diag & 2) && kept0 >= 0)
                     {
+                        cf *pl = reinterpret_cast<cf *>(po) + kept0;
+                        const unsigned step = 16u / chan.sub;
+                        const bool full = obase + LOUT <= M;
 #pragma unroll
                         for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
                         {
-                            const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
-                            if (idx < M)
-                            {
-                                const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
-                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
-                            }
+                            const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
+                            if (full || o0 + 16 * (mu0 - MU0_FIRST) < M)
+                                __builtin_nontemporal_store(v, pl);
+                            pl += step;
                         }
                     }
                 }
@@ -1863,11 +1957,9 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         {
                             const int64_t idx = o0 + 16 * (mu0 - MU0_FIRST);
                             const int64_t kept = ke.index((unsigned)mu1 + 16u * (unsigned)(mu0 - MU0_FIRST));
+                            const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
                             if (idx < M && kept >= 0)
-                            {
-                                const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
                                 __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + kept);
-                            }
                         }
                     }
                 }
@@ -1975,22 +2067,12 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                                            ncob[32 + 2 * (lane >> 2) + (lane & 1)]);
                     const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
                     if (po != nullptr && !(diag & 2))
-                    {
-#pragma unroll
-                        for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                        {
-                            const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
-                            if (idx < M)
-                            {
-                                cf v;
-                                if constexpr (NCO)
-                                    v = cmul_v<false>(c[mu0], cmul_v<false>(wl, ncob[mu0 - MU0_FIRST]));
-                                else
-                                    v = cmul_v<false>(c[mu0], wl);
-                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
-                            }
-                        }
-                    }
+                        store_lane_rows<16 - MU0_FIRST, 32>(reinterpret_cast<cf *>(po) + o0, obase + LOUT <= M, o0, M, [&](int k) {
+                            if constexpr (NCO)
+                                return cmul_v<false>(c[MU0_FIRST + k], cmul_v<false>(wl, ncob[k]));
+                            else
+                                return cmul_v<false>(c[MU0_FIRST + k], wl);
+                        });
                 }
                 if (b >= EARLY_B && next_fast)
                     refill();
@@ -2029,39 +2111,49 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 const bool last = cp + 2 >= nch; // the w values die with the last pair: refill with the next block
                 cf a[16];
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int ch = 0; ch < 2; ch++)
                 {
-#pragma unroll
-                    for (int ch = 0; ch < 2; ch++)
+                    if (ch == 1 && cp + 1 >= nch) // odd count: an empty second half
                     {
-                        if (ch == 1 && cp + 1 >= nch) // odd count: an empty second half
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
                         {
                             a[4 * i + 2] = (cf){0.f, 0.f};
                             a[4 * i + 3] = (cf){0.f, 0.f};
-                            continue;
                         }
-                        const int c = cp + ch;
-                        const int par = (int)chan.slot[c] & 1;
+                        continue;
+                    }
+                    const int c = cp + ch;
+                    const int par = (int)chan.slot[c] & 1;
+                    cf tw[7];
+#pragma unroll
+                    for (int a8 = 1; a8 < 8; a8++)
+                        tw[a8 - 1] = (cf){chan.tw[c][2 * (a8 - 1)], chan.tw[c][2 * (a8 - 1) + 1]}; // W16^(a slot)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
                         const f2v *g0 = hp + (i * 16 + 8 * par) * 64 + lane;       // k2' = 0: q = s & 1       (+ a * 64 entries)
                         const f2v *g1 = hp + (i * 16 + 8 * (1 - par)) * 64 + lane; // k2' = 1: q = (1 - s) & 1
-                        cf z0 = cmul_v<false>(r[phys(i, 0)], g0[0]);
-                        cf z1 = cmul_v<false>(r[phys(i, 8)], g1[0]);
+                        cf t0[8], t1[8];
 #pragma unroll
-                        for (int a8 = 1; a8 < 8; a8++)
+                        for (int a8 = 0; a8 < 8; a8++)
                         {
-                            const cf tw = {chan.tw[c][2 * (a8 - 1)], chan.tw[c][2 * (a8 - 1) + 1]};
-                            z0 = cmac_v(z0, cmul_s<false>(r[phys(i, a8)], tw), g0[a8 * 64]);
-                            z1 = cmac_v(z1, cmul_s<false>(r[phys(i, a8 + 8)], tw), g1[a8 * 64]);
+                            t0[a8] = r[phys(i, a8)];
+                            t1[a8] = r[phys(i, a8 + 8)];
                         }
+                        const cf z0 = gather_mac<8, 64, 2, 4>(t0, tw, g0); // (round 5: table reads ahead of the products)
+                        const cf z1 = gather_mac<8, 64, 2, 4>(t1, tw, g1);
                         a[4 * i + 2 * ch] = z0 + z1;
                         a[4 * i + 2 * ch + 1] = cmul_v<true>(z0 - z1, twd[(i * 4 + 2) * 64 + lane]); // conj W512^(16 k1 + k0)
                     }
-                    if (last && i < EARLY_GROUPS && next_fast)
-                    {
+                }
+                if (last && next_fast)
+                {
+#pragma unroll
+                    for (int i = 0; i < EARLY_GROUPS; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
                             load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
-                    }
                 }
                 cf c[16];
                 inverse_tail256(a, c, twe, xa, lane);
@@ -2083,17 +2175,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 cf wl = ((sl & lane) & 1) ? (cf){-r0.x, -r0.y} : r0;
                 const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
                 if (cl < nch && !(diag & 2))
-                {
-#pragma unroll
-                    for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                    {
-                        const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
-                        if (idx < M)
-                        {
-                            __builtin_nontemporal_store(cmul_v<false>(c[mu0], wl), reinterpret_cast<cf *>(po) + idx);
-                        }
-                    }
-                }
+                    store_lane_rows<16 - MU0_FIRST, 32>(reinterpret_cast<cf *>(po) + o0, obase + LOUT <= M, o0, M,
+                                                        [&](int k) { return cmul_v<false>(c[MU0_FIRST + k], wl); });
             }
             }
             else
@@ -2115,20 +2198,30 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             {
                 const bool last = cp + 2 >= nch; // the w values die with the last pair: refill with the next block
                 cf a[16];
+                // (round 5: channel by channel, its seven twiddles in SGPRs before its first table gather; per group the 2 x 8 gathers
+                // fly under the products w[a] W4096^(a B): gather_mac)
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int ch = 0; ch < 2; ch++)
                 {
-#pragma unroll
-                    for (int ch = 0; ch < 2; ch++)
+                    if (ch == 1 && cp + 1 >= nch) // odd count: an empty second half
                     {
-                        if (ch == 1 && cp + 1 >= nch) // odd count: an empty second half
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
                         {
                             a[4 * i + 2] = (cf){0.f, 0.f};
                             a[4 * i + 3] = (cf){0.f, 0.f};
-                            continue;
                         }
-                        const int c = cp + ch;
-                        const int cb = (int)chan.bin[c], b = cb & 255, s = cb >> 8; // wave-uniform
+                        continue;
+                    }
+                    const int c = cp + ch;
+                    const int cb = (int)chan.bin[c], b = cb & 255, s = cb >> 8; // wave-uniform
+                    cf tw[7];
+#pragma unroll
+                    for (int a8 = 1; a8 < 8; a8++)
+                        tw[a8 - 1] = (cf){chan.tw[c][2 * (a8 - 1)], chan.tw[c][2 * (a8 - 1) + 1]}; // W4096^(a B)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
                         const int ik = (i - b) & 3;                                 // table group of kappa (kappa % 4)
                         const int d = lq - (b >> 2) - ((i < (b & 3)) ? 1 : 0);      // (k_low - b) >> 2, negative: a borrow from k2
                         const int lk = d & 63;
@@ -2137,24 +2230,26 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                         const int par = sp & 1;
                         const f2v *g0 = hp + (ik * 16 + 8 * par) * 64 + lane_k;       // k2' = 0: q = s' & 1       (+ a * 64 entries)
                         const f2v *g1 = hp + (ik * 16 + 8 * (1 - par)) * 64 + lane_k; // k2' = 1: q = (1 - s') & 1
-                        cf z0 = cmul_v<false>(r[phys(i, 0)], g0[0]);
-                        cf z1 = cmul_v<false>(r[phys(i, 8)], g1[0]);
+                        cf t0[8], t1[8];
 #pragma unroll
-                        for (int a8 = 1; a8 < 8; a8++)
+                        for (int a8 = 0; a8 < 8; a8++)
                         {
-                            const cf tw = {chan.tw[c][2 * (a8 - 1)], chan.tw[c][2 * (a8 - 1) + 1]}; // W4096^(a B)
-                            z0 = cmac_v(z0, cmul_s<false>(r[phys(i, a8)], tw), g0[a8 * 64]);
-                            z1 = cmac_v(z1, cmul_s<false>(r[phys(i, a8 + 8)], tw), g1[a8 * 64]);
+                            t0[a8] = r[phys(i, a8)];
+                            t1[a8] = r[phys(i, a8 + 8)];
                         }
+                        const cf z0 = gather_mac<8, 64, 2, 4>(t0, tw, g0);
+                        const cf z1 = gather_mac<8, 64, 2, 4>(t1, tw, g1);
                         a[4 * i + 2 * ch] = z0 + z1;
                         a[4 * i + 2 * ch + 1] = cmul_v<true>(z0 - z1, twd[(i * 4 + 2) * 64 + lane]); // conj W512^(16 k1 + k0)
                     }
-                    if (last && i < EARLY_GROUPS && next_fast)
-                    {
+                }
+                if (last && next_fast)
+                {
+#pragma unroll
+                    for (int i = 0; i < EARLY_GROUPS; i++)
 #pragma unroll
                         for (int j = 0; j < 16; j++)
                             load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
-                    }
                 }
                 cf c[16];
                 inverse_tail256(a, c, twe, xa, lane);
@@ -2174,25 +2269,16 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 float2 *po = chl ? chan.out[c1] : chan.out[cp];
                 const uint32_t pw = chl ? chan.pword[c1] : chan.pword[cp];
                 const int64_t o0 = obase + 2 * (lane >> 2) + (lane & 1);
-                const float2 pa = nco_phasor(0u - pw * (chan.abs0n0 + 8u * (uint32_t)o0));
+                const float2 pa = phasor(0u - pw * (chan.abs0n0 + 8u * (uint32_t)o0));
                 const cf wl = {pa.x, pa.y};
                 const f2v *rowp = rowt + (chl ? c1 : cp) * 16;
                 // decimation 24, 40, 56 (8 x sub): every sub-th output of this tail is a real output (KeepEvery; sub = 1: all of them)
                 if (chan.sub == 1u) // (wave-uniform: decimation 8 itself keeps its plain store loop)
                 {
                     if (cl < nch && !(diag & 2))
-                    {
-#pragma unroll
-                        for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
-                        {
-                            const int64_t idx = o0 + 32 * (mu0 - MU0_FIRST);
-                            if (idx < M)
-                            {
-                                const cf v = cmul_v<false>(c[mu0], cmul_v<false>(wl, rowp[mu0 - MU0_FIRST]));
-                                __builtin_nontemporal_store(v, reinterpret_cast<cf *>(po) + idx);
-                            }
-                        }
-                    }
+                        store_lane_rows<16 - MU0_FIRST, 32>(reinterpret_cast<cf *>(po) + o0, obase + LOUT <= M, o0, M, [&](int k) {
+                            return cmul_v<false>(c[MU0_FIRST + k], cmul_v<false>(wl, rowp[k]));
+                        });
                 }
                 else
                 {
@@ -2258,15 +2344,35 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                 {
+                    // (round 5: two sums at a time, their table reads requested ahead of the products: see the general form below)
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
+                    for (int qp = 0; qp < 4; qp += 2)
                     {
-                        const f2v *g = hp + (i * 16 + ((q - slot) & 3)) * 64 + lane; // + m0 * 256 entries
-                        cf acc = cmul_v<false>(r[phys(i, 4 * q)], g[0]);
-                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 1)], w1), g[256]);
-                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 2)], w2), g[512]);
-                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 3)], w3), g[768]);
-                        z[4 * i + q] = acc;
+                        cf gq[2][4], pr[2][4];
+#pragma unroll
+                        for (int q = 0; q < 2; q++)
+                        {
+                            const f2v *g = hp + (i * 16 + ((qp + q - slot) & 3)) * 64 + lane; // + m0 * 256 entries
+#pragma unroll
+                            for (int m0 = 0; m0 < 4; m0++)
+                                gq[q][m0] = g[256 * m0];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < 2; q++)
+                        {
+                            pr[q][0] = r[phys(i, 4 * (qp + q))];
+                            pr[q][1] = cmul_s<false>(r[phys(i, 4 * (qp + q) + 1)], w1);
+                            pr[q][2] = cmul_s<false>(r[phys(i, 4 * (qp + q) + 2)], w2);
+                            pr[q][3] = cmul_s<false>(r[phys(i, 4 * (qp + q) + 3)], w3);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; q++)
+                        {
+                            const cf e = cmac_v(cmul_v<false>(pr[q][0], gq[q][0]), pr[q][2], gq[q][2]);
+                            const cf o = cmac_v(cmul_v<false>(pr[q][1], gq[q][1]), pr[q][3], gq[q][3]);
+                            z[4 * i + qp + q] = e + o;
+                        }
                     }
                     if (last && i < EARLY_GROUPS && next_fast)
                     {
@@ -2340,15 +2446,36 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                     const int lk = d & 63;
                     const int lane_k = ((lk & 3) << 4) | (lk >> 2);        // the lane that holds kappa in group ik
                     const int sp = s + (d < 0 ? 1 : 0);
+                    // (round 5: two of the group's four sums at a time -- their eight gathers are requested first, the six products
+                    // y w fly under them, then the multiply-accumulates; round 4's form had every table read in front of its use)
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
+                    for (int qp = 0; qp < 4; qp += 2)
                     {
-                        const f2v *g = hp + (ik * 16 + ((q - sp) & 3)) * 64 + lane_k; // + m0 * 256 entries
-                        cf acc = cmul_v<false>(r[phys(i, 4 * q)], g[0]);
-                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 1)], w1), g[256]);
-                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 2)], w2), g[512]);
-                        acc = cmac_v(acc, cmul_s<false>(r[phys(i, 4 * q + 3)], w3), g[768]);
-                        z[4 * i + q] = acc;
+                        cf gq[2][4], pr[2][4];
+#pragma unroll
+                        for (int q = 0; q < 2; q++)
+                        {
+                            const f2v *g = hp + (ik * 16 + ((qp + q - sp) & 3)) * 64 + lane_k; // + m0 * 256 entries
+#pragma unroll
+                            for (int m0 = 0; m0 < 4; m0++)
+                                gq[q][m0] = g[256 * m0];
+                        }
+                        __builtin_amdgcn_sched_barrier(0); // (the gathers stay up here: see gather_mac)
+#pragma unroll
+                        for (int q = 0; q < 2; q++)
+                        {
+                            pr[q][0] = r[phys(i, 4 * (qp + q))];
+                            pr[q][1] = cmul_s<false>(r[phys(i, 4 * (qp + q) + 1)], w1);
+                            pr[q][2] = cmul_s<false>(r[phys(i, 4 * (qp + q) + 2)], w2);
+                            pr[q][3] = cmul_s<false>(r[phys(i, 4 * (qp + q) + 3)], w3);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; q++)
+                        {
+                            const cf e = cmac_v(cmul_v<false>(pr[q][0], gq[q][0]), pr[q][2], gq[q][2]);
+                            const cf o = cmac_v(cmul_v<false>(pr[q][1], gq[q][1]), pr[q][3], gq[q][3]);
+                            z[4 * i + qp + q] = e + o;
+                        }
                     }
                     if (last && i < EARLY_GROUPS && next_fast)
                     {
@@ -2369,7 +2496,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 }
                 // mix-down: output o = obase + 64 (mu0 - first) + lane of the call belongs to input sample abs0n0 + 4 o: a lane factor
                 // (exact 32-bit phase) times the channel's row phasor (256 input samples per row)
-                const float2 pa = nco_phasor(0u - chan.pword[ch] * (chan.abs0n0 + 4u * (uint32_t)(obase + lane)));
+                const float2 pa = phasor(0u - chan.pword[ch] * (chan.abs0n0 + 4u * (uint32_t)(obase + lane)));
                 const cf wl = {pa.x, pa.y};
                 const f2v *rowp = rowt + ch * 16;
                 // decimation 12, 20, 28, ... (4 x sub): every sub-th output of this tail is a real output (KeepEvery, as in the
@@ -2468,7 +2595,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             if constexpr (NCO)
             {
                 // SPEC §3.2: output m = obase + 64 r + lane is rotated by phasor(phi0 + delta m) = A(lane) * B(r)
-                const float2 pa = nco_phasor(nco_phi0 + nco_delta * ((uint32_t)obase + (uint32_t)lane));
+                const float2 pa = phasor(nco_phi0 + nco_delta * ((uint32_t)obase + (uint32_t)lane));
                 const cf a_lane = {pa.x, pa.y};
 #pragma unroll
                 for (int mu0 = MU0_FIRST; mu0 < 16; mu0++)
@@ -2559,7 +2686,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
             cf a_lane = {1.0f, 0.0f};
             if constexpr (NCO)
             {
-                const float2 pa = nco_phasor(nco_phi0 + nco_delta * ((uint32_t)obase + (uint32_t)lane));
+                const float2 pa = phasor(nco_phi0 + nco_delta * ((uint32_t)obase + (uint32_t)lane));
                 a_lane = (cf){pa.x, pa.y};
             }
             (void)a_lane;
@@ -3064,7 +3191,9 @@ hipError_t launch_fft_rows(const LaunchArgs &a)
     }
 }
 
-#ifdef IF_FIR_FFT_HAZARD_PROBE // (tests/test_host.py: one instantiation, the decimate-by-2 tail with its 16-byte stores)
+#ifdef IF_FIR_FFT_ONLY // (development: ONE instantiation, e.g. -DIF_FIR_FFT_ONLY='4,true,false,false,17,false,false', to read its code)
+__attribute__((used)) static auto *const if_fir_fft_only_kernel = &fir_fft_kernel<IF_FIR_FFT_ONLY>;
+#elif defined(IF_FIR_FFT_HAZARD_PROBE) // (tests/test_host.py: one instantiation, the decimate-by-2 tail with its 16-byte stores)
 template __global__ void fir_fft_kernel<IF_FIR_FFT_ROWS, true, false, false, 2, false, false>(
     const f2v *, f2v *, const f2v *, const f2v *, int, int64_t, int32_t, int64_t, int64_t, int64_t, unsigned int *,
     unsigned long long *, int32_t, uint32_t, uint32_t, chan_arg_t<2>, uint32_t, void *, int32_t, int32_t, int64_t, int32_t);
@@ -3196,6 +3325,20 @@ static void bank_tan_forward(float *tw1, float *tw2)
         }
         for (int g = 0; g < 4; g++)
             tan_fft16_entries(-PI2 * (double)(4 * g + i) / 256.0, tw2 + 2 * (i * 60 + g), 4);
+    }
+}
+
+// the phasor tables of lds_phasor, at bytes [6 KB, 8 KB) of the image: P1[k] = exp(j 2 pi k / 128), P2[k] = exp(j 2 pi k / 16384)
+void fft_phasor_tables(float *tables)
+{
+    const double PI2 = 6.283185307179586476925286766559;
+    float *pht = tables + 6144 / 4;
+    for (int k = 0; k < 128; k++)
+    {
+        pht[2 * k + 0] = (float)cos(PI2 * (double)k / 128.0);
+        pht[2 * k + 1] = (float)sin(PI2 * (double)k / 128.0);
+        pht[2 * (128 + k) + 0] = (float)cos(PI2 * (double)k / 16384.0);
+        pht[2 * (128 + k) + 1] = (float)sin(PI2 * (double)k / 16384.0);
     }
 }
 
@@ -3332,6 +3475,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                     }
 #if IF_FIR_FFT_TAN
         bank_tan_forward(tw1, tw2); // (the 512-point inverse keeps its tables: twd, twe above)
+        fft_phasor_tables(tables);
 #endif
         return;
     }
@@ -3365,6 +3509,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                 }
 #if IF_FIR_FFT_TAN
         bank_tan_forward(tw1, tw2);
+        fft_phasor_tables(tables);
 #endif
         return;
     }
@@ -3409,6 +3554,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
             }
             for (int n2 = 0; n2 < 16; n2++)
                 tan_fft16_entries(-PI2 * (double)n2 / 256.0, twd + 2 * n2, 16);
+            fft_phasor_tables(tables);
         }
 #else
         (void)full_rate;
@@ -3470,6 +3616,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
         tan_fft16_entries(-PI2 * (double)lane / 1024.0, twd + 2 * lane, 64);
     for (int mu2 = 0; mu2 < 4; mu2++) // inverse, middle pass: b = W64^mu2
         tan_fft16_entries(-PI2 * (double)mu2 / 64.0, twe + 2 * mu2, 4);
+    fft_phasor_tables(tables);
 #endif
 }
 

@@ -62,6 +62,7 @@ def main():
     sums = []
     for name, v, f in pairs:       # one launch each: the outputs' checksum (a launch that skips blocks looks fast)
         y.zero_()
+        torch.cuda.synchronize()   # (zero_ runs on torch's stream, the filter on the context's)
         f.reset()
         f.process_device(src.data_ptr(), y.data_ptr(), n)
         f.synchronize()
