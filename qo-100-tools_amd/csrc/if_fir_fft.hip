@@ -758,6 +758,19 @@ __device__ __forceinline__ void inverse_tail256(cf (&a)[16], cf (&c)[16], const 
     fft16<true>(c); // over k0 -> mu0
 }
 
+// The same for the filter-bank images (round 5): the twiddle conj W256^(k0 mu1) between the two transforms sits on the INPUTS of the
+// second one in (cos, tan) form -- input k0 of lane 4 mu1 + low carries conj(b)^k0, b = W256^mu1 (table twet[e * 16 + mu1], the 15
+// entries of fft16_tw) -- 88 packed instructions where the 15 multiplies + the plain transform are 110.
+__device__ __forceinline__ void inverse_tail256_tan(cf (&a)[16], cf (&c)[16], const f2v *twet, const XAddr &xa, int lane)
+{
+    xst16<XROW>(xa.wx, a);
+    xld16<8>(xa.rx, a);
+    fft16<true>(a); // over k1 -> mu1
+    xst16<XROW>(xa.wy, a);
+    xld16<8>(xa.ry, c);
+    fft16_tw<true, 16>(c, twet + (lane >> 2)); // over k0 -> mu0
+}
+
 // decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
 // (4 x 16 x 16, tools/fft_model.py inverse_dec4) produces y[4m'] directly: lane = 4*mu1+mu2, slot mu0 -> y_D[64*mu0+lane]
 __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], const f2v *twd, const f2v *twe, const XAddr &xa,
@@ -804,6 +817,12 @@ __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16],
 // In batches of NB terms (registers: the next batch's gathers are hoisted above this batch's arithmetic by the scheduler, so
 // two batches of table entries are live at a time): per batch the NB gathers are requested first, the products d w -- which need
 // no table -- are formed while they fly, and the multiply-accumulates run as NA interleaved partial sums.
+#ifndef IF_FIR_GM_NA
+#define IF_FIR_GM_NA 2 // partial sums (4 with batches of 8 or 16 spills; 2 x 4: 240 VGPRs)
+#endif
+#ifndef IF_FIR_GM_NB
+#define IF_FIR_GM_NB 8 // terms per batch (4: 1 % slower, profiles/r05_filter_bank_ab.txt)
+#endif
 template <int N, int GS, int NA, int NB>
 __device__ __forceinline__ cf gather_mac(const cf (&d)[N], const cf (&tw)[N - 1], const f2v *g)
 {
@@ -1650,7 +1669,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 if (wanted)
                 {
                     cf c[16];
-                    inverse_tail256(a, c, twe, xa, lane);
+                    inverse_tail256_tan(a, c, twe, xa, lane);
                     // this lane's channel: its buffer (pointer table in LDS) and the call-constant mix-down phase
                     // exp(-j 2 pi s (abs0 + n0) / 16) = W16^(s rot_e) (table entries 16..31: the 16th roots of unity)
                     float2 *po = reinterpret_cast<float2 *const *>(smem + LDS_QPTR)[4 * b + cs];
@@ -1872,18 +1891,20 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                     for (int n2 = 1; n2 < 16; n2++)
                         tw[n2 - 1] = (cf){chan.tw[cq + ch][2 * (n2 - 1)], chan.tw[cq + ch][2 * (n2 - 1) + 1]}; // W4096^(n2 B)
+                    // the lane that holds kappa: (k_low - b) >> 2 = lq - (b >> 2), one less in the groups below b % 4 (a borrow) -- two
+                    // lanes per channel, picked per group by a wave-uniform test (round 4 recomputed them per group)
+                    const int lk0 = (lq - (b >> 2)) & 63, lk1 = (lk0 - 1) & 63;
+                    const int lane_k0 = ((lk0 & 3) << 4) | (lk0 >> 2), lane_k1 = ((lk1 & 3) << 4) | (lk1 >> 2);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                     {
                         const int ik = (i - b) & 3;                            // table group of kappa (kappa % 4)
-                        const int d = lq - (b >> 2) - ((i < (b & 3)) ? 1 : 0); // (k_low - b) >> 2, negative: a borrow from k2
-                        const int lk = d & 63;
-                        const int lane_k = ((lk & 3) << 4) | (lk >> 2);        // the lane that holds kappa in group ik
+                        const int lane_k = (i < (b & 3)) ? lane_k1 : lane_k0;
                         cf t[16];
 #pragma unroll
                         for (int n2 = 0; n2 < 16; n2++)
                             t[n2] = r[phys(i, n2)];
-                        a[4 * i + ch] = gather_mac<16, 64, 2, 4>(t, tw, hp + (ik * 16) * 64 + lane_k);
+                        a[4 * i + ch] = gather_mac<16, 64, IF_FIR_GM_NA, IF_FIR_GM_NB>(t, tw, hp + (ik * 16) * 64 + lane_k);
                     }
                 }
                 if (last && next_fast)
@@ -1895,7 +1916,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                             load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
                 }
                 cf c[16];
-                inverse_tail256(a, c, twe, xa, lane);
+                inverse_tail256_tan(a, c, twe, xa, lane);
                 if (last && next_fast)
                 {
 #pragma unroll
@@ -2050,7 +2071,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                 if (wanted)
                 {
                     cf c[16];
-                    inverse_tail256(a, c, twe, xa, lane);
+                    inverse_tail256_tan(a, c, twe, xa, lane);
                     // lane = 4 mu1 + 2 ch + mu2, slot mu0 -> y_s[32 mu0 + 2 mu1 + mu2], s = 2 (2 b + ch) + par.  Mix-down: the call
                     // constant W16^(s rot_e) (16th roots: table entries 16..31) times (-1)^(s m), m = obase + 32 (..) + 2 mu1 + mu2
                     // with obase even: the sign is (-1)^(s mu2)
@@ -2141,8 +2162,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                             t0[a8] = r[phys(i, a8)];
                             t1[a8] = r[phys(i, a8 + 8)];
                         }
-                        const cf z0 = gather_mac<8, 64, 2, 4>(t0, tw, g0); // (round 5: table reads ahead of the products)
-                        const cf z1 = gather_mac<8, 64, 2, 4>(t1, tw, g1);
+                        const cf z0 = gather_mac<8, 64, IF_FIR_GM_NA, IF_FIR_GM_NB>(t0, tw, g0); // (round 5: table reads ahead of the products)
+                        const cf z1 = gather_mac<8, 64, IF_FIR_GM_NA, IF_FIR_GM_NB>(t1, tw, g1);
                         a[4 * i + 2 * ch] = z0 + z1;
                         a[4 * i + 2 * ch + 1] = cmul_v<true>(z0 - z1, twd[(i * 4 + 2) * 64 + lane]); // conj W512^(16 k1 + k0)
                     }
@@ -2156,7 +2177,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                             load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
                 }
                 cf c[16];
-                inverse_tail256(a, c, twe, xa, lane);
+                inverse_tail256_tan(a, c, twe, xa, lane);
                 if (last && next_fast)
                 {
 #pragma unroll
@@ -2219,17 +2240,21 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
 #pragma unroll
                     for (int a8 = 1; a8 < 8; a8++)
                         tw[a8 - 1] = (cf){chan.tw[c][2 * (a8 - 1)], chan.tw[c][2 * (a8 - 1) + 1]}; // W4096^(a B)
+                    // the lane that holds kappa and the parity of s' = s + cy: (k_low - b) >> 2 = lq - (b >> 2), one less in the groups below
+                    // b % 4 (a borrow); negative: a borrow from k2 (cy = 1).  Two variants per channel, picked per group by a
+                    // wave-uniform test (round 4 recomputed them per group): entry offsets of the halves q = s' & 1 and 1 - q
+                    const int d0 = lq - (b >> 2), d1 = d0 - 1;
+                    const int lk0 = d0 & 63, lk1 = d1 & 63;
+                    const int par0 = (s + (d0 < 0 ? 1 : 0)) & 1, par1 = (s + (d1 < 0 ? 1 : 0)) & 1;
+                    const int e0a = (((lk0 & 3) << 4) | (lk0 >> 2)) + 512 * par0, e0b = e0a + 512 - 1024 * par0;
+                    const int e1a = (((lk1 & 3) << 4) | (lk1 >> 2)) + 512 * par1, e1b = e1a + 512 - 1024 * par1;
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                     {
                         const int ik = (i - b) & 3;                                 // table group of kappa (kappa % 4)
-                        const int d = lq - (b >> 2) - ((i < (b & 3)) ? 1 : 0);      // (k_low - b) >> 2, negative: a borrow from k2
-                        const int lk = d & 63;
-                        const int lane_k = ((lk & 3) << 4) | (lk >> 2);             // the lane that holds kappa in group ik
-                        const int sp = (s + (d < 0 ? 1 : 0)) & 15;
-                        const int par = sp & 1;
-                        const f2v *g0 = hp + (ik * 16 + 8 * par) * 64 + lane_k;       // k2' = 0: q = s' & 1       (+ a * 64 entries)
-                        const f2v *g1 = hp + (ik * 16 + 8 * (1 - par)) * 64 + lane_k; // k2' = 1: q = (1 - s') & 1
+                        const bool bor = i < (b & 3);
+                        const f2v *g0 = hp + ik * 1024 + (bor ? e1a : e0a); // k2' = 0: q = s' & 1       (+ a * 64 entries)
+                        const f2v *g1 = hp + ik * 1024 + (bor ? e1b : e0b); // k2' = 1: q = (1 - s') & 1
                         cf t0[8], t1[8];
 #pragma unroll
                         for (int a8 = 0; a8 < 8; a8++)
@@ -2237,8 +2262,8 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                             t0[a8] = r[phys(i, a8)];
                             t1[a8] = r[phys(i, a8 + 8)];
                         }
-                        const cf z0 = gather_mac<8, 64, 2, 4>(t0, tw, g0);
-                        const cf z1 = gather_mac<8, 64, 2, 4>(t1, tw, g1);
+                        const cf z0 = gather_mac<8, 64, IF_FIR_GM_NA, IF_FIR_GM_NB>(t0, tw, g0);
+                        const cf z1 = gather_mac<8, 64, IF_FIR_GM_NA, IF_FIR_GM_NB>(t1, tw, g1);
                         a[4 * i + 2 * ch] = z0 + z1;
                         a[4 * i + 2 * ch + 1] = cmul_v<true>(z0 - z1, twd[(i * 4 + 2) * 64 + lane]); // conj W512^(16 k1 + k0)
                     }
@@ -2252,7 +2277,7 @@ __global__ __launch_bounds__(512, 2) void fir_fft_kernel(const f2v *__restrict__
                             load_row<I16, LAUX, EDGE>(r, nsrd, lane, phys(i, j));
                 }
                 cf c[16];
-                inverse_tail256(a, c, twe, xa, lane);
+                inverse_tail256_tan(a, c, twe, xa, lane);
                 if (last && next_fast)
                 {
 #pragma unroll
@@ -3304,6 +3329,16 @@ static void tan_fft16_entries(double th, float *out, int stride)
 }
 
 // the filter banks' forward passes 2 and 3 (first stage) in (cos, tan) form, as in the decimate-by-4 image (fft_build_tables)
+// the filter-bank images' table between the two transforms of the small inverse (inverse_tail256_tan): twet[e * 16 + mu1], b = W256^mu1
+static void bank_tan_inverse(float *twe)
+{
+    const double PI2 = 6.283185307179586476925286766559;
+    for (int e = 0; e < 2 * 1024; e++)
+        twe[e] = 0.0f;
+    for (int mu1 = 0; mu1 < 16; mu1++)
+        tan_fft16_entries(-PI2 * (double)mu1 / 256.0, twe + 2 * mu1, 16);
+}
+
 static void bank_tan_forward(float *tw1, float *tw2)
 {
     const double PI2 = 6.283185307179586476925286766559;
@@ -3474,7 +3509,8 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                         hp[2 * ((i * 16 + 8 * half + a8) * 64 + lane) + 1] = (float)im;
                     }
 #if IF_FIR_FFT_TAN
-        bank_tan_forward(tw1, tw2); // (the 512-point inverse keeps its tables: twd, twe above)
+        bank_tan_forward(tw1, tw2); // (the 512-point inverse keeps twd above)
+        bank_tan_inverse(twe);
         fft_phasor_tables(tables);
 #endif
         return;
@@ -3509,6 +3545,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
                 }
 #if IF_FIR_FFT_TAN
         bank_tan_forward(tw1, tw2);
+        bank_tan_inverse(twe);
         fft_phasor_tables(tables);
 #endif
         return;
