@@ -1004,8 +1004,11 @@ def main():
                        "device": f.device_info()},
             "conditioning": {"device_ms": round(conditioning_ms, 1), "extra_passes_of_the_step": cond_passes,
                              "passes_covering_the_opening_barrier": BARRIER_COVER_STEPS if use_dist else 0,
-                             "note": "untimed GPU work ahead of the W warm-up steps (comparison measurements + passes "
-                                     "of the same step) so that the timed steps run in the settled power state; "
+                             "extras_order": "before" if args.extras_first else "after",
+                             "note": "untimed GPU work ahead of the W warm-up steps: passes of the same step (and, only with "
+                                     "--extras-first = extras_order 'before', the comparison measurements, as in the records up to "
+                                     "round 3; since round 4 they run BEHIND the timed steps, which alone moves `value` by about "
+                                     "6 %: profiles/r04_bench_order.txt) so that the timed steps run in the settled power state; "
                                      "multi-rank runs queue further untimed passes in front of the opening barrier so "
                                      "that the device is not idle during its host round trip"},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -21,6 +21,42 @@
 
 #define MAX_CHANNELS 16
 
+/* a command-line number: the whole argument must parse and lie in [lMin, lMax] (atoi would turn "-1" into 4 billion taps and
+ * "x" into 0, which the chunk arithmetic below divides by -- ADVICE r4) */
+static uint8_t parse_u32(const char *pszArg, long lMin, long lMax, uint32_t *pulOut)
+{
+    char *pszEnd = NULL;
+    const long lVal = strtol(pszArg, &pszEnd, 10);
+
+    if(pszEnd == pszArg || *pszEnd || lVal < lMin || lVal > lMax)
+        return 0;
+    *pulOut = (uint32_t)lVal;
+    return 1;
+}
+
+/* the output pattern goes to snprintf as a format: it must hold exactly one conversion, a plain %u (anything else -- %s, %n, two
+ * %u, none -- is undefined behaviour or one file for all channels) */
+static uint8_t pattern_ok(const char *pszPattern)
+{
+    unsigned uConversions = 0;
+
+    for(const char *p = pszPattern; *p; p++)
+    {
+        if(*p != '%')
+            continue;
+        if(p[1] == '%')
+        {
+            p++;
+            continue;
+        }
+        if(p[1] != 'u')
+            return 0;
+        uConversions++;
+        p++;
+    }
+    return uConversions == 1 && strlen(pszPattern) < 400;
+}
+
 static size_t read_fully(void *pBuf, size_t ulSize, size_t ulCount, FILE *pIn)
 {
     size_t ulGot = 0;
@@ -43,12 +79,14 @@ int main(int argc, char **argv)
     double dWidth = 0.02, adCentre[MAX_CHANNELS];
     const char *pszPattern = "channel_%u.cf32";
 
+    uint8_t ubArgsOk = 1;
+
     for(int i = 1; i + 1 < argc; i += 2)
     {
         if(!strcmp(argv[i], "-t"))
-            ulTaps = (uint32_t)atoi(argv[i + 1]);
+            ubArgsOk &= parse_u32(argv[i + 1], 1, 4096, &ulTaps);
         else if(!strcmp(argv[i], "-d"))
-            ulDecimation = (uint32_t)atoi(argv[i + 1]);
+            ubArgsOk &= parse_u32(argv[i + 1], 4, 64, &ulDecimation);
         else if(!strcmp(argv[i], "-w"))
             dWidth = atof(argv[i + 1]);
         else if(!strcmp(argv[i], "-f"))
@@ -63,11 +101,19 @@ int main(int argc, char **argv)
         else if(!strcmp(argv[i], "-i"))
             ubInt16 = !strcmp(argv[i + 1], "s16");
         else if(!strcmp(argv[i], "-c"))
-            ulChunk = (uint32_t)atoi(argv[i + 1]);
+            ubArgsOk &= parse_u32(argv[i + 1], 64, 1L << 28, &ulChunk);
         else if(!strcmp(argv[i], "-g"))
             lDevice = atoi(argv[i + 1]);
         else
             ulChannels = 0, i = argc;
+    }
+    /* validated before any arithmetic: decimation a multiple of 4 in 4..64 (the channelizer's tails), taps 1..4096, chunk 64..2^28,
+     * the pattern one %u */
+    if(!ubArgsOk || (ulDecimation & 3u) || !pattern_ok(pszPattern) || !(dWidth > 0.0 && dWidth < 0.5))
+    {
+        fprintf(stderr, "if_fir_channelize: bad argument (taps 1..4096, decimation 4, 8, ..., 64, chunk 64..2^28 samples, half width in "
+                        "(0, 0.5), pattern with exactly one %%u)\n");
+        ulChannels = 0;
     }
     if(!ulChannels)
     {

@@ -75,3 +75,15 @@ def test_channelizer_program(gpu_ok, tmp_path):
         l2, mx = oracle.err_metrics(y, ref)
         assert l2 <= 1e-6 and mx <= 1e-6, (c, l2, mx)
     assert b"200003 samples in, 3126 out per channel, 3 channels" in run.stderr
+
+
+def test_channelizer_program_validates_its_arguments_before_any_arithmetic():
+    """`-d 0` or a non-numeric `-d` divided by zero, negative counts wrapped to billions, and the `-o` pattern went to
+    snprintf as it came.  The program now refuses such arguments with exit code 2 before it touches the library (CPU test: no
+    GPU is needed to be told that the arguments are bad)."""
+    exe = os.path.join(ROOT, "qo-100-tools_amd", "host", "if_fir_channelize")
+    assert os.path.exists(exe), "build() first"
+    for bad in (["-d", "0"], ["-d", "x"], ["-d", "6"], ["-d", "128"], ["-t", "-5"], ["-t", "0"], ["-c", "5"], ["-c", "-1"],
+                ["-o", "a%s"], ["-o", "nothing"], ["-o", "a%u%u"], ["-o", "a%n%u"], ["-w", "0"], ["-w", "0.7"]):
+        run = subprocess.run([exe, "-f", "0.1"] + bad, stdin=subprocess.DEVNULL, capture_output=True, text=True, timeout=60)
+        assert run.returncode == 2 and "bad argument" in run.stderr, (bad, run.returncode, run.stderr[:200])

@@ -713,6 +713,53 @@ def test_filter_bank_table_images(fir):
             assert np.max(np.abs(g16[(i * 16 + n2) * 64 + lane] - g)) <= 2e-7 * scale * 2, (i, n2)
 
 
+def test_phasor_tables_and_the_banks_small_inverse_table(fir):
+    """Round 5: every (cos, tan) table image carries the phasor tables P1[k] = exp(j 2 pi k / 2^7), P2[k] = exp(j 2 pi k / 2^14) at bytes
+    [6 KB, 8 KB) (lds_phasor: a 32-bit phase -> phasor with two table reads and a second-order polynomial for the low 18 bits,
+    instead of two sincospif); the numpy model of that arithmetic stays within 2e-7 of the exact phasor over random and edge
+    phases.  The filter-bank images hold the twiddles between the two transforms of their small inverse as (cos, tan) entries of
+    b = W256^mu1 (inverse_tail256_tan)."""
+    taps = fir.bpf_design(255, 0.0, 0.02)
+    imgs = [fir.debug_fft_tables(taps, 4), fir.debug_fft_tables(taps, 1), fir.debug_fft_tables(taps, 8),
+            fir.debug_fft_tables_bank(taps, 8), fir.debug_fft_tables_bank(taps, 16), fir.debug_fft_tables_bank(taps, 8, parity=1)]
+    k = np.arange(128)
+    p1 = np.exp(2j * np.pi * k / 128.0).astype(np.complex64)
+    p2 = np.exp(2j * np.pi * k / 16384.0).astype(np.complex64)
+    for im in imgs:
+        pht = im["tw1"][768:1024]          # bytes 6144 .. 8191 of the image
+        assert np.array_equal(pht[:128], p1) and np.array_equal(pht[128:], p2)
+    # the kernel's arithmetic in float32 (lds_phasor)
+    rng = np.random.default_rng(5)
+    ph = np.concatenate([rng.integers(0, 2 ** 32, 200000, dtype=np.uint64), np.array([0, 1, 2 ** 18 - 1, 2 ** 18, 2 ** 25 - 1, 2 ** 32 - 1], dtype=np.uint64)])
+    a = p1[(ph >> 25).astype(np.int64)]
+    b = p2[((ph >> 18) & 127).astype(np.int64)]
+    th = ((ph & 0x3FFFF).astype(np.float32) * np.float32(1.4629180792671596e-9)).astype(np.float32)
+    lo = (np.float32(1.0) - np.float32(0.5) * th * th).astype(np.float32) + 1j * th
+    got = ((a * b).astype(np.complex64) * lo.astype(np.complex64)).astype(np.complex64)
+    exact = np.exp(2j * np.pi * ph.astype(np.float64) / 2.0 ** 32)
+    assert np.max(np.abs(got - exact)) < 2e-7
+    # the banks' table between the two transforms of the small inverse: entry e of b = W256^mu1 at [e * 16 + mu1]
+    for im in imgs[3:]:
+        twe = im["twe"]
+        for mu1 in (0, 1, 5, 15):
+            th0 = -2.0 * np.pi * mu1 / 256.0
+            def ent(theta, cref=0.0):
+                c = np.cos(theta)
+                if abs(c) < 9.3e-10:
+                    c = np.copysign(9.313225746154785e-10, c)
+                c = float(np.float32(c))
+                return np.float32(c / cref if cref else c), np.float32(np.sin(theta) / c), c
+            e0 = ent(4 * th0)
+            assert twe[0 * 16 + mu1].real == e0[0] and twe[0 * 16 + mu1].imag == e0[1]
+            e2 = ent(12 * th0, e0[2])
+            assert twe[2 * 16 + mu1].real == e2[0] and twe[2 * 16 + mu1].imag == e2[1]
+            for q in range(4):
+                bq = th0 - 2.0 * np.pi * q / 16.0
+                e = ent(bq)
+                assert twe[(3 + 3 * q) * 16 + mu1].real == e[0] and twe[(3 + 3 * q) * 16 + mu1].imag == e[1]
+        assert not np.any(twe[15 * 16:])   # the rest of the 8 KB slot is unused
+
+
 def test_host_table_builders_under_sanitizers(tmp_path):
     """The HOST side of csrc/if_fir_fft.hip -- fft_build_tables for every image (single-channel, full-rate, bank 8 even / odd, bank
     16), fft_build_tables_odd, the decimation-8 routing -- compiled with AddressSanitizer + UBSan (CPU only: hipcc --offload-host-only)
