@@ -531,19 +531,21 @@ def test_lds_exchange_order_gate_flags_a_reordered_probe_and_passes_the_build():
     tool = _exchange_tool()
     csrc = os.path.join(ROOT, "qo-100-tools_amd", "csrc")
     src = os.path.join(csrc, "if_fir_fft.hip")
-    tags = tool.tagged_lines(src)
-    lw = [k for k, v in tags.items() if v == "W"][0]
-    lr = [k for k, v in tags.items() if v == "R"][0]
+    tags = tool.tagged_lines(src)          # over if_fir_fft.hip and the parts it includes: {(file name, line): 'W' | 'R'}
+    fw, lw = [k for k, v in tags.items() if v == "W"][0]
+    fr, lr = [k for k, v in tags.items() if v == "R"][0]
+    fw, fr = os.path.join(csrc, fw), os.path.join(csrc, fr)
     assert len(tags) >= 12     # the two helpers and every call site
+    assert {k[0] for k in tags} >= {"if_fir_fft_dev.h", "if_fir_fft_odd.inc"}
 
     def stream(*parts):
         out = ["0000000000001000 <_ZN6if_fir14fir_fft_kernelILi4EEEvv>:"]
         for kind, n in parts:
             if kind == "W":
-                out.append("; %s:%d" % (src, lw))
+                out.append("; %s:%d" % (fw, lw))
                 out += ["\tds_write_b64 v1, v[2:3] offset:%d  // 000000001000: 0" % (136 * k) for k in range(n)]
             elif kind == "R":
-                out.append("; %s:%d" % (src, lr))
+                out.append("; %s:%d" % (fr, lr))
                 out += ["\tds_read2_b64 v[4:7], v9 offset0:%d offset1:%d  // 000000001000: 0" % (2 * k, 2 * k + 1) for k in range(n // 2)]
                 out += ["\tds_read_b64 v[4:5], v9  // 000000001000: 0"] * (n % 2)
             elif kind == "T":    # table reads: another source line, ignored wherever they stand
@@ -588,7 +590,7 @@ def test_lds_exchange_order_gate_flags_a_reordered_probe_and_passes_the_build():
         assert not bad, (o, bad[:3])
         assert len(fam) >= 16 and min(fam.values()) >= 4, (o, len(fam))    # every kernel: exchange 2 (four rounds) at least
     # the fence macro of round 4 is gone: the order no longer depends on a switch
-    assert "LDS_FENCE" not in open(src).read()
+    assert not any("LDS_FENCE" in open(f).read() for f in tool.source_files(src))
 
 
 def test_bench_line_contract_on_the_committed_run():

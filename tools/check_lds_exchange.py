@@ -40,30 +40,43 @@ FAMILY = ("fir_fft_kernel", "fir_odd_kernel")
 _CALL_W, _CALL_R = re.compile(r"\bxst16<"), re.compile(r"\bxld16<")
 
 
+SOURCE_PARTS = ("if_fir_fft.hip", "if_fir_fft_dev.h", "if_fir_fft_odd.inc", "if_fir_fft_kernel.inc", "if_fir_fft_tails_bank.inc",
+                "if_fir_fft_tails_single.inc", "if_fir_fft_launch.inc")
+
+
+def source_files(source):
+    """the kernel source and the parts it includes (round 5: if_fir_fft.hip is a driver that includes its families)"""
+    d = os.path.dirname(os.path.abspath(source))
+    return [os.path.join(d, f) for f in SOURCE_PARTS if os.path.exists(os.path.join(d, f))]
+
+
 def tagged_lines(source):
-    """{line number: 'W' | 'R'}: the helpers' own lines (tagged LDSX:STORE / LDSX:LOAD) and every line that calls one of them (a DS
-    instruction the compiler merged from two accesses of different inlined copies carries a CALL SITE's line)"""
+    """{(file name, line number): 'W' | 'R'}: the helpers' own lines (tagged LDSX:STORE / LDSX:LOAD) and every line that calls one of
+    them (a DS instruction the compiler merged from two accesses of different inlined copies carries a CALL SITE's line), over the
+    kernel source and every part it includes"""
     out, helpers = {}, set()
-    for k, ln in enumerate(open(source), 1):
-        code = ln.split("//")[0]
-        w = bool(_CALL_W.search(code)) or "LDSX:STORE" in code
-        r = bool(_CALL_R.search(code)) or "LDSX:LOAD" in code
-        if w and r:
-            raise SystemExit("check_lds_exchange: %s:%d holds a store and a load of the exchanges: the gate classifies by source line" % (source, k))
-        if w:
-            out[k] = "W"
-        if r:
-            out[k] = "R"
-        if "LDSX:STORE" in code and "reinterpret_cast" in code:
-            helpers.add("W")
-        if "LDSX:LOAD" in code and "reinterpret_cast" in code:
-            helpers.add("R")
+    for path in source_files(source):
+        base = os.path.basename(path)
+        for k, ln in enumerate(open(path), 1):
+            code = ln.split("//")[0]
+            w = bool(_CALL_W.search(code)) or "LDSX:STORE" in code
+            r = bool(_CALL_R.search(code)) or "LDSX:LOAD" in code
+            if w and r:
+                raise SystemExit("check_lds_exchange: %s:%d holds a store and a load of the exchanges: the gate classifies by source line" % (path, k))
+            if w:
+                out[(base, k)] = "W"
+            if r:
+                out[(base, k)] = "R"
+            if "LDSX:STORE" in code and "reinterpret_cast" in code:
+                helpers.add("W")
+            if "LDSX:LOAD" in code and "reinterpret_cast" in code:
+                helpers.add("R")
     if helpers != {"R", "W"}:
         raise SystemExit("check_lds_exchange: %s must hold the LDSX:STORE and LDSX:LOAD helper lines (found %s)" % (source, sorted(helpers)))
     return out
 
 
-def scan_text(text, tags, source_base, where=""):
+def scan_text(text, tags, source_base=None, where=""):
     """(violations, {kernel: exchanges}) of a line-annotated disassembly"""
     bad, units = [], {}
     kern, cur, known = None, None, False
@@ -86,7 +99,7 @@ def scan_text(text, tags, source_base, where=""):
         m = _LINE.match(ln.strip())
         if m:
             known = int(m.group(2)) > 0
-            cur = tags.get(int(m.group(2))) if os.path.basename(m.group(1)) == source_base else None
+            cur = tags.get((os.path.basename(m.group(1)), int(m.group(2))))
             continue
         d = isa_tools.instr(ln)
         if not d or kern is None or not d[0].startswith("ds_"):
