@@ -501,13 +501,21 @@ def time_config(fir, name, backend, x, dev, stream, steps, warmup, names):
             "output_nonzero": nonzero}
 
 
-def time_filter_bank(fir, x, dev, stream, channels=8, taps_n=255, decim=8, log2n=28, steps=20):
+def time_filter_bank(fir, x, dev, stream, channels=8, taps_n=255, decim=8, log2n=28, steps=20, own_centres=False):
     """The filter bank (if_fir_channelizer_process_device: `channels` fs/16 channels from ONE pass over the resident wideband
     stream, decimation 8 = 2x oversampled) timed like an extra config, channel 0 checked against a context that mixes, filters
-    and decimates that one channel (extra.filter_bank; never part of `value`)."""
+    and decimates that one channel (extra.filter_bank; never part of `value`).  own_centres (round 5, extra.filter_bank_own_centres):
+    every channel at its own centre on the fs/4096 grid, if_fir_channelizer_process_device_freq -- what QO-100's narrow-band
+    channels need (they do not sit on fs/16)."""
     n = min(1 << log2n, x.numel() // 2)
     taps = fir.bpf_design(taps_n, 0.0, 0.02)
     slots = [(2 * c + 1) % 16 for c in range(channels)] if channels <= 8 else list(range(channels))
+    centres = [(((256 * s + 37 + 11 * c) + 2048) % 4096 - 2048) / 4096.0 for c, s in enumerate(slots)]
+
+    def bank(fb, ptrs):
+        if own_centres:
+            return fb.channelizer_process_device_freq(centres, x.data_ptr(), ptrs, n)
+        return fb.channelizer_process_device(slots, x.data_ptr(), ptrs, n)
     with fir.IfFir(taps, decim, 0, device=dev.index) as fb:
         fb.set_stream(stream.cuda_stream)
         m = fb.out_count(n)
@@ -515,19 +523,19 @@ def time_filter_bank(fir, x, dev, stream, channels=8, taps_n=255, decim=8, log2n
         ptrs = [o.data_ptr() for o in outs]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(100):   # ~100 ms of its own launches
-            fb.channelizer_process_device(slots, x.data_ptr(), ptrs, n)
+            bank(fb, ptrs)
         e0.record(stream)
         for _ in range(steps):
-            fb.channelizer_process_device(slots, x.data_ptr(), ptrs, n)
+            bank(fb, ptrs)
         e1.record(stream)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
         fb.reset()
-        fb.channelizer_process_device(slots, x.data_ptr(), ptrs, n)
+        bank(fb, ptrs)
         fb.synchronize()
     with fir.IfFir(taps, decim, 0, device=dev.index) as f1:
         s0 = slots[0]
-        f1.set_nco(s0 / 16.0 if s0 <= 8 else s0 / 16.0 - 1.0)
+        f1.set_nco(centres[0] if own_centres else (s0 / 16.0 if s0 <= 8 else s0 / 16.0 - 1.0))
         f1.set_stream(stream.cuda_stream)
         ref = torch.empty(2 * m, dtype=torch.float32, device=dev)
         f1.process_device(x.data_ptr(), ref.data_ptr(), n)
@@ -535,8 +543,9 @@ def time_filter_bank(fir, x, dev, stream, channels=8, taps_n=255, decim=8, log2n
         rel = ((ref - outs[0]).abs().max() / ref.abs().max()).item()
     del outs, ref
     bytes_alg = (8.0 + channels * 8.0 / decim) * n
-    return {"workload": "%d channels (slots %s) x (%d-tap prototype, decimate-by-%d) from one 2^%d-sample stream" %
-                        (channels, slots, taps_n, decim, log2n),
+    return {"workload": "%d channels (%s) x (%d-tap prototype, decimate-by-%d) from one 2^%d-sample stream" %
+                        (channels, "centres %s on the fs/4096 grid" % [round(c, 5) for c in centres] if own_centres else "slots %s" % slots,
+                         taps_n, decim, log2n),
             "kernel_ms": round(ms, 4), "steps": steps, "input_msamples_per_s": round(n / ms / 1e3, 1),
             "algorithmic_bytes": bytes_alg, "hbm_gbs": round(bytes_alg / (ms * 1e-3) / 1e9, 1),
             "frac": round(bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -803,6 +812,18 @@ def main():
                 extra["filter_bank"] = time_filter_bank(fir, x, dev, stream, log2n=WORKLOADS[args.workload][2])
             except Exception as e:   # noqa: BLE001 - context only, never fatal
                 extra["filter_bank"] = {"error": repr(e)}
+            # round 5: the same eight channels at their own centres (general forms), decimation 8, 16 and 64
+            fbo = {}
+            for dec_o in (8, 16, 64):
+                try:
+                    torch.cuda.empty_cache()
+                    if i16:
+                        raise RuntimeError("float32 stream only")
+                    fbo["decimate_by_%d" % dec_o] = time_filter_bank(fir, x, dev, stream, decim=dec_o, log2n=WORKLOADS[args.workload][2],
+                                                                     own_centres=True)
+                except Exception as e:   # noqa: BLE001 - context only, never fatal
+                    fbo["decimate_by_%d" % dec_o] = {"error": repr(e)}
+            extra["filter_bank_own_centres"] = fbo
     if args.extras_first:
         measure_extras()
     condition(args.condition_ms, 20)       # and passes of the step itself right in front of the warm-up

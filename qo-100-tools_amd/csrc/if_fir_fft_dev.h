@@ -181,20 +181,47 @@ __device__ __forceinline__ void bfly4_tw(cf x0, cf x1, cf x2, cf x3, cf e1, cf e
 // 16-point transform of v[j] b^j (inverse: v[j] conj(b)^j), natural order in and out.  Table (host, tan_fft16_entries): entries
 // 0..2 = b^4, b^8, b^12 (first radix-4 stage; its outputs still owe b^i); entries 3 + 3 q + (i - 1) = b^i W16^(i q), i = 1..3 (the
 // owed factor merged with the transform's own twiddle); entry k at e[k * STRIDE].
-template <bool INV, int STRIDE>
+// IF_FIR_FFT_TW_PREFETCH (round 5 experiment, profiles/r05_table_prefetch_ab.txt): 1 = all 15 entries are requested at the top and a
+// scheduling barrier keeps them there (the scheduler otherwise sinks every table read down to its use: one LDS round trip per
+// butterfly, waited for on the spot); 0 = as written, the compiler places them
+#ifndef IF_FIR_FFT_TW_PREFETCH
+#define IF_FIR_FFT_TW_PREFETCH 1
+#endif
+// PF (round 5, profiles/r05_table_prefetch_ab.txt): all 15 entries are requested at the top and a scheduling barrier keeps them
+// there.  Left to itself the machine scheduler sinks every table read down to its use -- it minimises live registers -- and the
+// wave waits one LDS round trip per butterfly, on the spot; with the reads up front the headline kernel runs 6 % faster on the same
+// instructions.  30 registers for the duration of the transform: the tails that have none to spare pass PF = false.
+template <bool INV, int STRIDE, bool PF = (IF_FIR_FFT_TW_PREFETCH != 0)>
 __device__ __forceinline__ void fft16_tw(cf (&v)[16], const f2v *e)
 {
     cf y[4][4];
+    if constexpr (PF)
     {
-        const cf e1 = e[0], e2 = e[STRIDE], e3 = e[2 * STRIDE];
+        cf ee[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++)
+            ee[k] = e[k * STRIDE];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            bfly4_tw<INV>(v[i], v[i + 4], v[i + 8], v[i + 12], e1, e2, e3, y[0][i], y[1][i], y[2][i], y[3][i]);
-    }
+            bfly4_tw<INV>(v[i], v[i + 4], v[i + 8], v[i + 12], ee[0], ee[1], ee[2], y[0][i], y[1][i], y[2][i], y[3][i]);
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        bfly4_tw<INV>(y[q][0], y[q][1], y[q][2], y[q][3], e[(3 + 3 * q) * STRIDE], e[(4 + 3 * q) * STRIDE], e[(5 + 3 * q) * STRIDE],
-                      v[q], v[q + 4], v[q + 8], v[q + 12]);
+        for (int q = 0; q < 4; q++)
+            bfly4_tw<INV>(y[q][0], y[q][1], y[q][2], y[q][3], ee[3 + 3 * q], ee[4 + 3 * q], ee[5 + 3 * q], v[q], v[q + 4], v[q + 8], v[q + 12]);
+    }
+    else
+    {
+        {
+            const cf e1 = e[0], e2 = e[STRIDE], e3 = e[2 * STRIDE];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                bfly4_tw<INV>(v[i], v[i + 4], v[i + 8], v[i + 12], e1, e2, e3, y[0][i], y[1][i], y[2][i], y[3][i]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            bfly4_tw<INV>(y[q][0], y[q][1], y[q][2], y[q][3], e[(3 + 3 * q) * STRIDE], e[(4 + 3 * q) * STRIDE], e[(5 + 3 * q) * STRIDE],
+                          v[q], v[q + 4], v[q + 8], v[q + 12]);
+    }
 }
 
 // The same with the table in two pieces (round 4, full-rate pipeline): the first stage's entries at s1[0], s1[S1], s1[2 S1]; the
@@ -727,6 +754,7 @@ __device__ __forceinline__ void inverse_tail256(cf (&a)[16], cf (&c)[16], const 
 // The same for the filter-bank images (round 5): the twiddle conj W256^(k0 mu1) between the two transforms sits on the INPUTS of the
 // second one in (cos, tan) form -- input k0 of lane 4 mu1 + low carries conj(b)^k0, b = W256^mu1 (table twet[e * 16 + mu1], the 15
 // entries of fft16_tw) -- 88 packed instructions where the 15 multiplies + the plain transform are 110.
+template <bool PF = (IF_FIR_FFT_TW_PREFETCH != 0)>
 __device__ __forceinline__ void inverse_tail256_tan(cf (&a)[16], cf (&c)[16], const f2v *twet, const XAddr &xa, int lane)
 {
     xst16<XROW>(xa.wx, a);
@@ -734,7 +762,7 @@ __device__ __forceinline__ void inverse_tail256_tan(cf (&a)[16], cf (&c)[16], co
     fft16<true>(a); // over k1 -> mu1
     xst16<XROW>(xa.wy, a);
     xld16<8>(xa.ry, c);
-    fft16_tw<true, 16>(c, twet + (lane >> 2)); // over k0 -> mu0
+    fft16_tw<true, 16, PF>(c, twet + (lane >> 2)); // over k0 -> mu0
 }
 
 // decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
@@ -757,6 +785,7 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
 // the same with the twiddles in (cos, tan) form on the inputs of the two 16-point transforms (round 4; tables tb = LDS_TWE,
 // tc = LDS_TWD): 4-point inverse over k2' (plain) -> X -> iFFT16 over k1, inputs carry conj(W64^mu2)^k1 -> Y -> iFFT16 over k0,
 // inputs carry conj(W1024^lane)^k0.  208 packed instructions where inverse_dec4 has 246.
+template <bool PF = (IF_FIR_FFT_TW_PREFETCH != 0)>
 __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16], const f2v *tb, const f2v *tc, const XAddr &xa, int lane)
 {
     cf a[16];
@@ -765,10 +794,10 @@ __device__ __forceinline__ void inverse_dec4_tan(const cf (&z)[16], cf (&c)[16],
         bfly4<true>(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3], a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
     xst16<XROW>(xa.wx, a);
     xld16<8>(xa.rx, a);
-    fft16_tw<true, 4>(a, tb + (lane & 3)); // over k1 -> mu1
+    fft16_tw<true, 4, PF>(a, tb + (lane & 3)); // over k1 -> mu1
     xst16<XROW>(xa.wy, a);
     xld16<8>(xa.ry, c);
-    fft16_tw<true, 64>(c, tc + lane); // over k0 -> mu0
+    fft16_tw<true, 64, PF>(c, tc + lane); // over k0 -> mu0
 }
 
 

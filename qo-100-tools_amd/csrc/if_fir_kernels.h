@@ -144,7 +144,7 @@ void fft_build_tables(const float *taps, int T, int ctaps, int D, uint32_t nco_d
 // streams and one inverse (fir_odd_kernel); *pOvlr = dropped 64-output rows of a block (2, 4 or 8).  False: no such tail (the
 // full-rate pipeline + selecting store serves the pair).
 bool fft_odd_tail(int T, int D, int *pF, int *pSub, int *pOvlr);
-constexpr int fft_odd_table_floats(int F) { return 2 * (F * 1024 + 256 + 768 + 1024 + 64 + 64); } // G_p | TB | TC | TWD | TWE | NCO
+constexpr int fft_odd_table_floats(int F) { return 2 * (F * 1024 + 256 + 768 + 1024 + 64 + 64 + 256); } // G_p | TB | TC | TWD | TWE | NCO | phasor tables (round 5)
 void fft_build_tables_odd(const float *taps, int T, int ctaps, int F, uint32_t nco_delta, double in_scale, float *tables);
 hipError_t launch_fft_odd(const LaunchArgs &a);
 int fft_overlap_rows(int T, int D);

@@ -448,7 +448,7 @@ def debug_fft_tables_odd(taps, decimation, complex_taps=False, nco_delta=0):
     """if_fir_debug_fft_tables_odd(): the odd-decimation kernel's table image (decimation 3, 9, 15, ...) as complex64 sections."""
     taps = np.ascontiguousarray(taps, dtype=np.float32)
     t = taps.size // 2 if complex_taps else taps.size
-    nfl = 10496
+    nfl = 10496 + 512
     out = np.zeros(nfl, dtype=np.float32)
     L = dev_lib()
     L.if_fir_debug_fft_tables_odd.restype = ctypes.c_uint32
@@ -458,7 +458,7 @@ def debug_fft_tables_odd(taps, decimation, complex_taps=False, nco_delta=0):
     if n != nfl:
         raise IfFirError("if_fir_debug_fft_tables_odd: (taps=%d, decimation=%d) is not served by the odd-decimation kernel" % (t, decimation))
     c = out.view(np.complex64)
-    return {"g": c[0:3072], "tb": c[3072:3328], "tc": c[3328:4096], "twd": c[4096:5120], "twe": c[5120:5184], "ncob": c[5184:5248]}
+    return {"g": c[0:3072], "tb": c[3072:3328], "tc": c[3328:4096], "twd": c[4096:5120], "twe": c[5120:5184], "ncob": c[5184:5248], "pht": c[5248:5504]}
 
 
 def debug_fft_schedule(nblocks, workgroups=256):

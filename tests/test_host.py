@@ -730,6 +730,8 @@ def test_phasor_tables_and_the_banks_small_inverse_table(fir):
     for im in imgs:
         pht = im["tw1"][768:1024]          # bytes 6144 .. 8191 of the image
         assert np.array_equal(pht[:128], p1) and np.array_equal(pht[128:], p2)
+    odd = fir.debug_fft_tables_odd(taps, 3)["pht"]     # the odd-decimation kernel's image: behind its NCO row phasors
+    assert np.array_equal(odd[:128], p1) and np.array_equal(odd[128:], p2)
     # the kernel's arithmetic in float32 (lds_phasor)
     rng = np.random.default_rng(5)
     ph = np.concatenate([rng.integers(0, 2 ** 32, 200000, dtype=np.uint64), np.array([0, 1, 2 ** 18 - 1, 2 ** 18, 2 ** 25 - 1, 2 ** 32 - 1], dtype=np.uint64)])
