@@ -187,6 +187,16 @@ __device__ __forceinline__ void bfly4_tw(cf x0, cf x1, cf x2, cf x3, cf e1, cf e
 #ifndef IF_FIR_FFT_TW_PREFETCH
 #define IF_FIR_FFT_TW_PREFETCH 1
 #endif
+// N table entries p[k STRIDE] requested together, and a scheduling barrier that keeps the requests here (round 5: see fft16_tw)
+template <int N, int STRIDE, bool PF = (IF_FIR_FFT_TW_PREFETCH != 0)>
+__device__ __forceinline__ void lds_fetch(cf (&w)[N], const f2v *p)
+{
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        w[k] = p[k * STRIDE];
+    if constexpr (PF)
+        __builtin_amdgcn_sched_barrier(0);
+}
 // PF (round 5, profiles/r05_table_prefetch_ab.txt): all 15 entries are requested at the top and a scheduling barrier keeps them
 // there.  Left to itself the machine scheduler sinks every table read down to its use -- it minimises live registers -- and the
 // wave waits one LDS round trip per butterfly, on the spot; with the reads up front the headline kernel runs 6 % faster on the same
@@ -227,20 +237,45 @@ __device__ __forceinline__ void fft16_tw(cf (&v)[16], const f2v *e)
 // The same with the table in two pieces (round 4, full-rate pipeline): the first stage's entries at s1[0], s1[S1], s1[2 S1]; the
 // second stage's from the SHARED table T of the triples (b, b^2, b^3 with the third as (c3 / c1, t3)) of b = W4096^m, m = 0..1023:
 // entry (b W16^q)^(j+1) = T_j[m + 256 q] at tq[1024 j + 256 q] (three arrays of 1024 entries; tq = T + tsw(m)).
-template <bool INV, int S1>
+// (PF: the 15 entries requested at the top, kept there by a scheduling barrier -- see fft16_tw)
+template <bool INV, int S1, bool PF = (IF_FIR_FFT_TW_PREFETCH != 0)>
 __device__ __forceinline__ void fft16_tw_T(cf (&v)[16], const f2v *s1, const f2v *tq)
 {
     cf y[4][4];
+    if constexpr (PF)
     {
-        const cf e1 = s1[0], e2 = s1[S1], e3 = s1[2 * S1];
+        cf ee[15];
+        ee[0] = s1[0];
+        ee[1] = s1[S1];
+        ee[2] = s1[2 * S1];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            ee[3 + 3 * q] = tq[256 * q];
+            ee[4 + 3 * q] = tq[1024 + 256 * q];
+            ee[5 + 3 * q] = tq[2048 + 256 * q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            bfly4_tw<INV>(v[i], v[i + 4], v[i + 8], v[i + 12], e1, e2, e3, y[0][i], y[1][i], y[2][i], y[3][i]);
-    }
+            bfly4_tw<INV>(v[i], v[i + 4], v[i + 8], v[i + 12], ee[0], ee[1], ee[2], y[0][i], y[1][i], y[2][i], y[3][i]);
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        bfly4_tw<INV>(y[q][0], y[q][1], y[q][2], y[q][3], tq[256 * q], tq[1024 + 256 * q], tq[2048 + 256 * q], v[q], v[q + 4], v[q + 8],
-                      v[q + 12]);
+        for (int q = 0; q < 4; q++)
+            bfly4_tw<INV>(y[q][0], y[q][1], y[q][2], y[q][3], ee[3 + 3 * q], ee[4 + 3 * q], ee[5 + 3 * q], v[q], v[q + 4], v[q + 8], v[q + 12]);
+    }
+    else
+    {
+        {
+            const cf e1 = s1[0], e2 = s1[S1], e3 = s1[2 * S1];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                bfly4_tw<INV>(v[i], v[i + 4], v[i + 8], v[i + 12], e1, e2, e3, y[0][i], y[1][i], y[2][i], y[3][i]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            bfly4_tw<INV>(y[q][0], y[q][1], y[q][2], y[q][3], tq[256 * q], tq[1024 + 256 * q], tq[2048 + 256 * q], v[q], v[q + 4], v[q + 8],
+                          v[q + 12]);
+    }
 }
 // Position of entry m in an array of T: the low five bits are mixed with bits 5..7 so that both users' gathers -- m = lane + 64 rho
 // + 256 q (last inverse pass) and m = 4 (lane / 16) + i + 16 (lane % 16) + 256 q (forward pass 3) -- put the 32 lanes of a half
@@ -737,14 +772,17 @@ struct DevQueue
 //   X: row transposition (one round of exchange 2): element j of lane (g, k1) -> lane (g, j), slot k1; iFFT16 over k1 -> mu1
 //   twiddle conj W256^(k0 mu1);  Y: element mu1 of lane (k0, low) -> lane 4 mu1 + low, slot k0;  iFFT16 over k0 -> mu0
 // result: lane = 4 mu1 + low, slot mu0
+template <bool PF = (IF_FIR_FFT_TW_PREFETCH != 0)>
 __device__ __forceinline__ void inverse_tail256(cf (&a)[16], cf (&c)[16], const f2v *twe, const XAddr &xa, int lane)
 {
     xst16<XROW>(xa.wx, a);
     xld16<8>(xa.rx, a);
+    cf we[15];
+    lds_fetch<15, 64, PF>(we, twe + 64 + lane); // (round 5: the 15 twiddles requested ahead of the transform)
     fft16<true>(a); // over k1 -> mu1
 #pragma unroll
     for (int mu1 = 1; mu1 < 16; mu1++)
-        a[mu1] = cmul_v<true>(a[mu1], twe[mu1 * 64 + lane]);
+        a[mu1] = cmul_v<true>(a[mu1], we[mu1 - 1]);
     // Y: wy + mu1 XROW = element (mu1, k0) of region `low`; ry + 8 k0
     xst16<XROW>(xa.wy, a);
     xld16<8>(xa.ry, c);
@@ -767,19 +805,21 @@ __device__ __forceinline__ void inverse_tail256_tan(cf (&a)[16], cf (&c)[16], co
 
 // decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
 // (4 x 16 x 16, tools/fft_model.py inverse_dec4) produces y[4m'] directly: lane = 4*mu1+mu2, slot mu0 -> y_D[64*mu0+lane]
+template <bool PF = (IF_FIR_FFT_TW_PREFETCH != 0)>
 __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], const f2v *twd, const f2v *twe, const XAddr &xa,
                                              int lane)
 {
-    cf a[16];
+    cf a[16], wd[16];
+    lds_fetch<16, 64, PF>(wd, twd + lane); // (round 5: the twiddles requested ahead of the butterflies; entries 4 i are unused ones)
 #pragma unroll
     for (int i = 0; i < 4; i++)
     {
         bfly4<true>(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3], a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
 #pragma unroll
         for (int mu2 = 1; mu2 < 4; mu2++)
-            a[4 * i + mu2] = cmul_v<true>(a[4 * i + mu2], twd[(i * 4 + mu2) * 64 + lane]);
+            a[4 * i + mu2] = cmul_v<true>(a[4 * i + mu2], wd[i * 4 + mu2]);
     }
-    inverse_tail256(a, c, twe, xa, lane);
+    inverse_tail256<PF>(a, c, twe, xa, lane);
 }
 
 // the same with the twiddles in (cos, tan) form on the inputs of the two 16-point transforms (round 4; tables tb = LDS_TWE,
