@@ -548,9 +548,10 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 #define IF_FIR_FFT_STORE_AUX 2
 #endif
 // decimate-by-4 tail: how many of the 4 batches of next-block row loads are issued during pass 3 (the rest behind the
-// small inverse).  4 fits without scratch since round 2 and measures the same (0.4546 vs 0.4549 ms): 3 is kept.
+// small inverse).  Round 2 measured 4 = 3 and kept 3; round 5, with the steady state's pass 1 no longer waiting for the previous
+// block's stores (IF_FIR_FFT_COLD_WAIT) the fourth batch's extra lead is worth 0.1-0.5 % (profiles/r05_table_prefetch_ab.txt): 4.
 #ifndef IF_FIR_FFT_EARLY_GROUPS
-#define IF_FIR_FFT_EARLY_GROUPS 3
+#define IF_FIR_FFT_EARLY_GROUPS 4
 #endif
 // the first block's rows are requested ahead of the table copy (head of the launch)
 #ifndef IF_FIR_FFT_TABLE_COPY_UNROLLED
