@@ -550,6 +550,9 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 // decimate-by-4 tail: how many of the 4 batches of next-block row loads are issued during pass 3 (the rest behind the
 // small inverse).  Round 2 measured 4 = 3 and kept 3; round 5, with the steady state's pass 1 no longer waiting for the previous
 // block's stores (IF_FIR_FFT_COLD_WAIT) the fourth batch's extra lead is worth 0.1-0.5 % (profiles/r05_table_prefetch_ab.txt): 4.
+#ifndef IF_FIR_FFT_COLD_WAIT
+#define IF_FIR_FFT_COLD_WAIT 1 // the cold load path drains its loads before it joins the steady-state path (if_fir_fft_kernel.inc)
+#endif
 #ifndef IF_FIR_FFT_EARLY_GROUPS
 #define IF_FIR_FFT_EARLY_GROUPS 4
 #endif
