@@ -14,12 +14,13 @@ import bench  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "fir255_dec4_2p28"
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # 1001/1002/1003: skip loads / stores / both
+lib_path = sys.argv[3] if len(sys.argv) > 3 else None    # a build with -DIF_FIR_FFT_STAMPS (tools/build_ab.sh stamps -DIF_FIR_FFT_STAMPS)
 taps_n, decim, log2n, _ = bench.WORKLOADS[wl]
 n = 1 << log2n
 fir = g.load_pkg().if_fir
 torch.cuda.set_device(0)
 x = torch.empty(2 * n, dtype=torch.float32, device="cuda")
-with fir.IfFir(fir.bpf_design(taps_n), decim, 0, dev=True) as f:
+with fir.IfFir(fir.bpf_design(taps_n), decim, 0, dev=True, lib_path=lib_path) as f:
     f.set_backend(fir.BACKEND_HIP_FFT)
     f.set_tuning(variant)
     y = torch.empty(2 * f.out_count(n), dtype=torch.float32, device="cuda")
@@ -39,7 +40,8 @@ with fir.IfFir(fir.bpf_design(taps_n), decim, 0, dev=True) as f:
             i0, i1 = np.flatnonzero(ok)[1], np.flatnonzero(ok)[-1]
             print("wave %d shader clock over iterations %d..%d: %.3f GHz" %
                   (w, i0, i1, (c[w][i1, 7] - c[w][i0, 0]) / ((s[w][i1, 7] - s[w][i0, 0]) * 10.0)))
-    names = ["top->loaded", "pass1", "exch1+pass2", "exch2", "pass3(+fold,issue)", "inverse", "stores"]
+    names = (["top->loaded", "pass1", "exch1+pass2", "exch2+take", "pass3+H+inv3", "exch2+inv2+exch1", "inv1+stores+loads"] if decim == 1 else
+             ["top->loaded", "pass1", "exch1+pass2", "exch2", "pass3(+fold,issue)", "inverse", "stores"])
     print(wl, 'variant', variant)
     for w in range(4):
         d = np.diff(s[w], axis=1) * 0.01   # us
