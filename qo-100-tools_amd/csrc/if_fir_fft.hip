@@ -14,11 +14,11 @@
 // waves of a 512-thread workgroup are independent; FFT blocks are handed out through an atomic queue.
 // FP32 VALU only (v_add/v_fma/v_pk_*), no MFMA.
 //
-// Build: this file is compiled seven times (csrc/Makefile) -- once per overlap length with -DIF_FIR_FFT_ROWS=4|8|16|32|48 (the
+// Build: this file is compiled twelve times (csrc/Makefile) -- once per overlap length with -DIF_FIR_FFT_ROWS=4|8|16|32|48 (the
 // kernel, its launcher and the explicit instantiation of launch_fft_rows<ROWS>; the 32-row unit also carries the two-partition
-// launches), once with -DIF_FIR_FFT_ODD (the odd-decimation kernel) and once with neither (host side: tables, routing predicates,
-// launch_fft) -- so that the instantiations compile
-// in parallel.
+// launches), once more per overlap length with -DIF_FIR_FFT_DEC2_UNIT on top (the decimate-by-2 tails: the copy of the kernel whose LDS
+// reads the compiler may pair, round 5), once with -DIF_FIR_FFT_ODD (the odd-decimation kernel) and once with none of them (host side:
+// tables, routing predicates, launch_fft) -- so that the instantiations compile in parallel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -45,7 +45,19 @@ namespace if_fir
 #endif // IF_FIR_FFT_ODD
 
 #ifdef IF_FIR_FFT_ROWS // ================= kernel + launchers: the per-overlap-length compilation units =================
+#if defined(IF_FIR_FFT_HAZARD_PROBE) && !defined(IF_FIR_FFT_DEC2_UNIT)
+#define IF_FIR_FFT_DEC2_UNIT 1 // (the probe instantiates the decimate-by-2 tail)
+#endif
+#ifdef IF_FIR_FFT_DEC2_UNIT // the decimate-by-2 tails' units: the compiler may pair this copy's LDS reads (if_fir_fft_kernel.inc)
+#define FIR_FFT_KERNEL_NAME fir_fft_kernel_paired
+#define FIR_FFT_KERNEL_ATTR
+#else
+#define FIR_FFT_KERNEL_NAME fir_fft_kernel
+#define FIR_FFT_KERNEL_ATTR IF_FIR_LDS_SINGLE_READS
+#endif
 #include "if_fir_fft_kernel.inc"
+#undef FIR_FFT_KERNEL_NAME
+#undef FIR_FFT_KERNEL_ATTR
 template <int ROWS>
 hipError_t launch_fft_rows(const LaunchArgs &a); // defined and explicitly instantiated in the unit compiled with IF_FIR_FFT_ROWS = ROWS
 hipError_t launch_fft_two_partitions(const LaunchArgs &a); // (in the 32-row unit)

@@ -316,6 +316,15 @@ constexpr int FFT_PART = 2048; // filters of 3074..4096 taps: two partitions of 
 constexpr int XROW = 136;             // bytes per 16-entry row of the exchange buffers (16*8 + 8 pad)
 constexpr int XREG = 16 * XROW + 32;  // one 16x16 region (+32 so that the 4 regions start on different banks)
 constexpr int XBUF = 4 * XREG;        // per-wave exchange buffer
+// (round 5) the X exchange's own region stride: with single ds_read_b64 (lanes 0-31 / 32-63 per LDS cycle, 64 banks) the reads of the lane rows
+// g = 0, 1 (and 2, 3) go out together, and their 16 x 136-byte rows must interleave on the banks: region stride = 128 bytes mod 256 (with
+// XREG's +32 the two rows collide on 8 of 64 banks: SQ_LDS_BANK_CONFLICT 12 % of the LDS cycles, profiles/r05_lds_single_reads.txt).  The Y
+// exchange keeps XREG: its stores (16 lanes per LDS cycle, 32 banks) need the +32, and no stride serves both its stores and its reads.
+#ifndef IF_FIR_FFT_XREGX_PAD
+#define IF_FIR_FFT_XREGX_PAD 0
+#endif
+constexpr int XREGX = 16 * XROW + IF_FIR_FFT_XREGX_PAD;
+static_assert(XREGX <= XREG, "the X exchange's regions fit the per-wave buffer");
 constexpr int FFT_WAVES = 8;
 static_assert(FFT_WAVES == (int)QB, "one slot of a block group per wave of the workgroup");
 constexpr int LDS_TW1 = 0, LDS_HP = 32768, LDS_TW2 = 65536, LDS_TWD = 65536 + 2048, LDS_TWE = LDS_TWD + 8192,
@@ -475,13 +484,13 @@ struct XAddr
 __device__ __forceinline__ XAddr xaddr_x(char *xb, int lane)
 {
     const int g = lane >> 4, m = lane & 15;
-    return XAddr{xb + g * XREG + m * 8, lds_opaque(xb + g * XREG + m * XROW), nullptr, nullptr};
+    return XAddr{xb + g * XREGX + m * 8, lds_opaque(xb + g * XREGX + m * XROW), nullptr, nullptr};
 }
 __device__ __forceinline__ XAddr xaddr_xy(char *xb, int lane)
 {
     const int g = lane >> 4, m = lane & 15;
     const int k0 = 4 * g + (m >> 2), low = m & 3;
-    return XAddr{xb + g * XREG + m * 8, lds_opaque(xb + g * XREG + m * XROW), xb + low * XREG + k0 * 8,
+    return XAddr{xb + g * XREGX + m * 8, lds_opaque(xb + g * XREGX + m * XROW), xb + low * XREG + k0 * 8,
                  lds_opaque(xb + (lane & 3) * XREG + (lane >> 2) * XROW)};
 }
 
@@ -553,8 +562,26 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 #ifndef IF_FIR_FFT_COLD_WAIT
 #define IF_FIR_FFT_COLD_WAIT 1 // the cold load path drains its loads before it joins the steady-state path (if_fir_fft_kernel.inc)
 #endif
+// (round 5, profiles/r05_lds_single_reads.txt) LDS reads as single ds_read_b64: the compiler's machine-level load/store optimizer pairs the
+// kernels' 8-byte LDS reads into ds_read2_b64 / ds_read2st64_b64, which the LDS serves in 8 cycles per pair on 32 banks, where two ds_read_b64 take
+// 2 cycles each on 64 banks (MI355X_MICROARCH.md, LDS); the LDS array was busy 60 % of the time in these kernels.  Per kernel, through the
+// subtarget feature (device pass only: the host pass does not know the feature); the IR-level vectorizer, which merges ADJACENT pairs, is
+// switched off for the units in csrc/Makefile (-mllvm -amdgpu-load-store-vectorizer=0).
+#ifndef IF_FIR_FFT_SINGLE_READS
+#define IF_FIR_FFT_SINGLE_READS 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && IF_FIR_FFT_SINGLE_READS
+#define IF_FIR_LDS_SINGLE_READS __attribute__((target("no-load-store-opt")))
+#else
+#define IF_FIR_LDS_SINGLE_READS
+#endif
 #ifndef IF_FIR_FFT_EARLY_GROUPS
 #define IF_FIR_FFT_EARLY_GROUPS 4
+#endif
+// (the tail that keeps every sub-th output, CHAN 1 = decimation 8, 12, ..., 64, computes 15 store offsets on top: with four early batches and
+// unpaired LDS reads two of its instantiations' cold paths needed 4 VGPRs of scratch; three batches there)
+#ifndef IF_FIR_FFT_EARLY_GROUPS_SUB
+#define IF_FIR_FFT_EARLY_GROUPS_SUB 3
 #endif
 // the first block's rows are requested ahead of the table copy (head of the launch)
 #ifndef IF_FIR_FFT_TABLE_COPY_UNROLLED

@@ -430,6 +430,11 @@ def test_no_overlap_save_instantiation_spills():
     # + 10 (round 4): the decimation-4 general form keeping every sub-th output (decimation 12, 20, ...) as its own instantiation
     # + 10 (round 4): the all-slots form with the context's NCO (a common offset of the slot grid)
     assert len(fft) == 244, len(fft)
+    # (round 5) the decimate-by-2 tails (CHAN 2, 3: 5 x 8 + 8 accumulating) are the copy of the kernel with paired LDS reads, all others the
+    # single-read kernel
+    paired = [k for k in fft if "fir_fft_kernel_paired" in k]
+    assert len(paired) == 48 and all(re.search(r"Li[23]ELb0ELb[01]E", k) for k in paired), len(paired)
+    assert not any(re.search(r"Li[23]ELb0ELb[01]E", k) for k in fft if "fir_fft_kernel_paired" not in k)
     for name, res in fft.items():
         assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
     # round 4: the odd-decimation kernel (blocks of 3 x 1024 samples): 2 overlap lengths x float32 / int16 x NCO x thinning
@@ -501,12 +506,14 @@ def test_wide_store_hazard_scanner_flags_the_round_3_form_and_passes_the_build()
             assert tool.count_wide_stores(text) >= 12, "the probe no longer holds the 16-byte stores of the decimate-by-2 tail"
             bad = tool.scan_text(text, "probe%d" % probe)
             assert bool(bad) == expect_bad, (probe, bad[:3])
-    objs = ["if_fir_fft_r%d.o" % r for r in (4, 8, 16, 32, 48)] + ["if_fir_fft_odd.o", "if_fir_kernels.o", "wb_detect.o"]
+    # (round 5: the decimate-by-2 tails, the only kernels of the overlap-save source with 16-byte stores, live in units of their own)
+    rows = (4, 8, 16, 32, 48)
+    objs = ["if_fir_fft_r%d.o" % r for r in rows] + ["if_fir_fft_d2_r%d.o" % r for r in rows] + ["if_fir_fft_odd.o", "if_fir_kernels.o", "wb_detect.o"]
     for o in objs:
         path = os.path.join(csrc, o)
         assert os.path.exists(path), "build() first: %s" % o
         text = tool.disassemble(path)
-        assert tool.count_wide_stores(text) > 0 or o == "if_fir_fft_odd.o", o      # (the odd-decimation kernel stores 8 bytes per lane)
+        assert tool.count_wide_stores(text) > 0 or o == "if_fir_fft_odd.o" or o.startswith("if_fir_fft_r"), o   # (8 bytes per lane there)
         assert not tool.scan_text(text, o), o
 
 
@@ -582,13 +589,14 @@ def test_lds_exchange_order_gate_flags_a_reordered_probe_and_passes_the_build():
         a = strip(tool.isa_tools.disassemble(plain))
         b = strip(tool.isa_tools.disassemble(os.path.join(td, "probe0.o")))
         assert a == b and len(a) > 3000
-    for o in ["if_fir_fft_r%d.o" % r for r in (4, 8, 16, 32, 48)] + ["if_fir_fft_odd.o"]:
+    rows = (4, 8, 16, 32, 48)
+    for o in ["if_fir_fft_r%d.o" % r for r in rows] + ["if_fir_fft_d2_r%d.o" % r for r in rows] + ["if_fir_fft_odd.o"]:
         path = os.path.join(csrc, o)
         assert os.path.exists(path), "build() first: %s" % o
         bad, units = tool.scan_text(tool.isa_tools.disassemble(path, lines=True), tags, base, o)
         fam = {k: n for k, n in units.items() if any(f in k for f in tool.FAMILY) and not k.endswith(".kd")}
         assert not bad, (o, bad[:3])
-        assert len(fam) >= 16 and min(fam.values()) >= 4, (o, len(fam))    # every kernel: exchange 2 (four rounds) at least
+        assert len(fam) >= (8 if "_d2_" in o else 16) and min(fam.values()) >= 4, (o, len(fam))    # every kernel: exchange 2 (four rounds) at least
     # the fence macro of round 4 is gone: the order no longer depends on a switch
     assert not any("LDS_FENCE" in open(f).read() for f in tool.source_files(src))
 
