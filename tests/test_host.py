@@ -601,6 +601,41 @@ def test_lds_exchange_order_gate_flags_a_reordered_probe_and_passes_the_build():
     assert not any("LDS_FENCE" in open(f).read() for f in tool.source_files(src))
 
 
+def test_lds_reads_are_single_in_the_single_read_kernels_and_paired_in_the_decimate_by_2_units():
+    """Round 5 (profiles/r05_lds_single_reads.txt): a ds_read2_b64 / ds_read2st64_b64 pair takes 8 LDS cycles on 32 banks, two ds_read_b64 take 2 each on
+    64 -- the overlap-save kernels are compiled so that the compiler forms no pairs (a per-kernel target attribute + the IR vectorizer off for their units),
+    except the decimate-by-2 tails, which live in units of their own and keep them.  Checked in the built objects: a toolchain that ignored the
+    attribute would still be correct, only slower -- this test is what would notice."""
+    import collections
+    import sys
+    csrc = os.path.join(ROOT, "qo-100-tools_amd", "csrc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_tools
+
+    def read_forms(obj):
+        per, kern = collections.defaultdict(collections.Counter), None
+        for ln in isa_tools.disassemble(os.path.join(csrc, obj)).splitlines():
+            lab = isa_tools.label(ln)
+            if lab is not None and not lab.startswith(".L") and "+0x" not in lab:
+                kern = lab
+                continue
+            d = isa_tools.instr(ln)
+            if d and kern and d[0].startswith("ds_read"):
+                per[kern][d[0]] += 1
+        return {k: v for k, v in per.items() if not k.endswith(".kd")}
+    for obj, name in (("if_fir_fft_r4.o", "fir_fft_kernel"), ("if_fir_fft_r32.o", "fir_fft_kernel"), ("if_fir_fft_odd.o", "fir_odd_kernel")):
+        assert os.path.exists(os.path.join(csrc, obj)), "build() first: %s" % obj
+        forms = {k: v for k, v in read_forms(obj).items() if name in k}
+        assert len(forms) >= 16, (obj, len(forms))
+        for k, v in forms.items():
+            assert "paired" not in k, k
+            assert set(v) == {"ds_read_b64"} and v["ds_read_b64"] >= 200, (obj, k[:90], dict(v))
+    forms = read_forms("if_fir_fft_d2_r4.o")
+    assert len(forms) == 8 and all("fir_fft_kernel_paired" in k for k in forms), list(forms)[:2]
+    for k, v in forms.items():
+        assert v["ds_read2_b64"] + v["ds_read2st64_b64"] >= 100, (k[:90], dict(v))
+
+
 def test_bench_line_contract_on_the_committed_run():
     """The bench.py JSON line of the last profiled run (profiles/*_bench.json, produced on the GPU box) carries every
     field the driver's contract names, with the right types, and its numbers are mutually consistent."""
