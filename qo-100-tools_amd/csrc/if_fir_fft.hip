@@ -50,7 +50,11 @@ namespace if_fir
 #endif
 #ifdef IF_FIR_FFT_DEC2_UNIT // the decimate-by-2 tails' units: the compiler may pair this copy's LDS reads (if_fir_fft_kernel.inc)
 #define FIR_FFT_KERNEL_NAME fir_fft_kernel_paired
+#ifdef IF_FIR_FFT_DEC2_SINGLE // (development: the decimate-by-2 tails with single reads as well)
+#define FIR_FFT_KERNEL_ATTR IF_FIR_LDS_SINGLE_READS
+#else
 #define FIR_FFT_KERNEL_ATTR
+#endif
 #else
 #define FIR_FFT_KERNEL_NAME fir_fft_kernel
 #define FIR_FFT_KERNEL_ATTR IF_FIR_LDS_SINGLE_READS

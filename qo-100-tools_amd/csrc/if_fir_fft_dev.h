@@ -575,6 +575,15 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 #else
 #define IF_FIR_LDS_SINGLE_READS
 #endif
+// decimate-by-2 tail: its 16 entries of H per group in rolling batches of this many (0: read where they are used, round 4's form)
+#ifndef IF_FIR_FFT_DEC2_PF
+#define IF_FIR_FFT_DEC2_PF 0
+#endif
+// decimate-by-2 tail: which table reads of its two small inverses are requested ahead (bit 0: the 4-point stage's, bit 1: the 16-point stages')
+#ifndef IF_FIR_FFT_DEC2_PFI
+#define IF_FIR_FFT_DEC2_PFI 0
+#endif
+__device__ __forceinline__ constexpr int dec2_order(int j) { return j; }
 #ifndef IF_FIR_FFT_EARLY_GROUPS
 #define IF_FIR_FFT_EARLY_GROUPS 4
 #endif
@@ -836,7 +845,7 @@ __device__ __forceinline__ void inverse_tail256_tan(cf (&a)[16], cf (&c)[16], co
 
 // decimate-by-4 tail of one block: the 4 spectral aliases are folded in-lane (k2 = k2' + 4j) and a 1024-point inverse
 // (4 x 16 x 16, tools/fft_model.py inverse_dec4) produces y[4m'] directly: lane = 4*mu1+mu2, slot mu0 -> y_D[64*mu0+lane]
-template <bool PF = (IF_FIR_FFT_TW_PREFETCH != 0)>
+template <bool PF = (IF_FIR_FFT_TW_PREFETCH != 0), bool PFE = PF>
 __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], const f2v *twd, const f2v *twe, const XAddr &xa,
                                              int lane)
 {
@@ -850,7 +859,7 @@ __device__ __forceinline__ void inverse_dec4(const cf (&z)[16], cf (&c)[16], con
         for (int mu2 = 1; mu2 < 4; mu2++)
             a[4 * i + mu2] = cmul_v<true>(a[4 * i + mu2], wd[i * 4 + mu2]);
     }
-    inverse_tail256<PF>(a, c, twe, xa, lane);
+    inverse_tail256<PFE>(a, c, twe, xa, lane);
 }
 
 // the same with the twiddles in (cos, tan) form on the inputs of the two 16-point transforms (round 4; tables tb = LDS_TWE,
