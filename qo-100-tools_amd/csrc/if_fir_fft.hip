@@ -16,8 +16,8 @@
 //
 // Build: this file is compiled twelve times (csrc/Makefile) -- once per overlap length with -DIF_FIR_FFT_ROWS=4|8|16|32|48 (the
 // kernel, its launcher and the explicit instantiation of launch_fft_rows<ROWS>; the 32-row unit also carries the two-partition
-// launches), once more per overlap length with -DIF_FIR_FFT_DEC2_UNIT on top (the decimate-by-2 tails: the copy of the kernel whose LDS
-// reads the compiler may pair, round 5), once with -DIF_FIR_FFT_ODD (the odd-decimation kernel) and once with none of them (host side:
+// launches), once more per overlap length with -DIF_FIR_FFT_DEC2_UNIT on top (the decimate-by-2 tails' instantiations,
+// round 5), once with -DIF_FIR_FFT_ODD (the odd-decimation kernel) and once with none of them (host side:
 // tables, routing predicates, launch_fft) -- so that the instantiations compile in parallel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -48,19 +48,14 @@ namespace if_fir
 #if defined(IF_FIR_FFT_HAZARD_PROBE) && !defined(IF_FIR_FFT_DEC2_UNIT)
 #define IF_FIR_FFT_DEC2_UNIT 1 // (the probe instantiates the decimate-by-2 tail)
 #endif
-#ifdef IF_FIR_FFT_DEC2_UNIT // the decimate-by-2 tails' units: the compiler may pair this copy's LDS reads (if_fir_fft_kernel.inc)
-#define FIR_FFT_KERNEL_NAME fir_fft_kernel_paired
-#ifdef IF_FIR_FFT_DEC2_SINGLE // (development: the decimate-by-2 tails with single reads as well)
-#define FIR_FFT_KERNEL_ATTR IF_FIR_LDS_SINGLE_READS
-#else
+// (round 5: the decimate-by-2 tails, CHAN 2 and 3, are instantiated in units of their own, -DIF_FIR_FFT_DEC2_UNIT: more units to compile in
+// parallel, and per-family build flags for tools/build_ab.sh; -DIF_FIR_FFT_DEC2_PAIRED, development: those units without the single-read attribute)
+#if defined(IF_FIR_FFT_DEC2_UNIT) && defined(IF_FIR_FFT_DEC2_PAIRED)
 #define FIR_FFT_KERNEL_ATTR
-#endif
 #else
-#define FIR_FFT_KERNEL_NAME fir_fft_kernel
 #define FIR_FFT_KERNEL_ATTR IF_FIR_LDS_SINGLE_READS
 #endif
 #include "if_fir_fft_kernel.inc"
-#undef FIR_FFT_KERNEL_NAME
 #undef FIR_FFT_KERNEL_ATTR
 template <int ROWS>
 hipError_t launch_fft_rows(const LaunchArgs &a); // defined and explicitly instantiated in the unit compiled with IF_FIR_FFT_ROWS = ROWS

@@ -575,13 +575,15 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 #else
 #define IF_FIR_LDS_SINGLE_READS
 #endif
-// decimate-by-2 tail: its 16 entries of H per group in rolling batches of this many (0: read where they are used, round 4's form)
+// decimate-by-2 tail: its 16 entries of H per group in rolling batches of this many (0: read where they are used, round 4's form; 8 spills).
+// With batches of 4 and the 4-point stage's twiddles of its small inverses requested ahead the tail runs on single LDS reads like the others:
+// 255 taps /2 -2.6 %, int16 -4.3 %, with the NCO -5.4 % against round 4's form with paired reads (profiles/r05_lds_single_reads.txt, last section)
 #ifndef IF_FIR_FFT_DEC2_PF
-#define IF_FIR_FFT_DEC2_PF 0
+#define IF_FIR_FFT_DEC2_PF 4
 #endif
 // decimate-by-2 tail: which table reads of its two small inverses are requested ahead (bit 0: the 4-point stage's, bit 1: the 16-point stages')
 #ifndef IF_FIR_FFT_DEC2_PFI
-#define IF_FIR_FFT_DEC2_PFI 0
+#define IF_FIR_FFT_DEC2_PFI 1 // (bit 1 spills)
 #endif
 __device__ __forceinline__ constexpr int dec2_order(int j) { return j; }
 #ifndef IF_FIR_FFT_EARLY_GROUPS

@@ -430,11 +430,8 @@ def test_no_overlap_save_instantiation_spills():
     # + 10 (round 4): the decimation-4 general form keeping every sub-th output (decimation 12, 20, ...) as its own instantiation
     # + 10 (round 4): the all-slots form with the context's NCO (a common offset of the slot grid)
     assert len(fft) == 244, len(fft)
-    # (round 5) the decimate-by-2 tails (CHAN 2, 3: 5 x 8 + 8 accumulating) are the copy of the kernel with paired LDS reads, all others the
-    # single-read kernel
-    paired = [k for k in fft if "fir_fft_kernel_paired" in k]
-    assert len(paired) == 48 and all(re.search(r"Li[23]ELb0ELb[01]E", k) for k in paired), len(paired)
-    assert not any(re.search(r"Li[23]ELb0ELb[01]E", k) for k in fft if "fir_fft_kernel_paired" not in k)
+    # (round 5) 48 of them are the decimate-by-2 tails (CHAN 2, 3: 5 x 8 + 8 accumulating), instantiated in units of their own
+    assert sum(1 for k in fft if re.search(r"Li[23]ELb0ELb[01]E", k)) == 48
     for name, res in fft.items():
         assert res["ScratchSize"] == 0 and res["VGPRs Spill"] == 0 and res["VGPRs"] <= 256, (name, res)
     # round 4: the odd-decimation kernel (blocks of 3 x 1024 samples): 2 overlap lengths x float32 / int16 x NCO x thinning
@@ -601,11 +598,10 @@ def test_lds_exchange_order_gate_flags_a_reordered_probe_and_passes_the_build():
     assert not any("LDS_FENCE" in open(f).read() for f in tool.source_files(src))
 
 
-def test_lds_reads_are_single_in_the_single_read_kernels_and_paired_in_the_decimate_by_2_units():
+def test_lds_reads_are_single_in_the_built_kernels():
     """Round 5 (profiles/r05_lds_single_reads.txt): a ds_read2_b64 / ds_read2st64_b64 pair takes 8 LDS cycles on 32 banks, two ds_read_b64 take 2 each on
-    64 -- the overlap-save kernels are compiled so that the compiler forms no pairs (a per-kernel target attribute + the IR vectorizer off for their units),
-    except the decimate-by-2 tails, which live in units of their own and keep them.  Checked in the built objects: a toolchain that ignored the
-    attribute would still be correct, only slower -- this test is what would notice."""
+    64 -- the overlap-save kernels are compiled so that the compiler forms no pairs (a per-kernel target attribute + the IR vectorizer off for their
+    units).  Checked in the built objects: a toolchain that ignored the attribute would still be correct, only slower -- this test is what would notice."""
     import collections
     import sys
     csrc = os.path.join(ROOT, "qo-100-tools_amd", "csrc")
@@ -623,17 +619,13 @@ def test_lds_reads_are_single_in_the_single_read_kernels_and_paired_in_the_decim
             if d and kern and d[0].startswith("ds_read"):
                 per[kern][d[0]] += 1
         return {k: v for k, v in per.items() if not k.endswith(".kd")}
-    for obj, name in (("if_fir_fft_r4.o", "fir_fft_kernel"), ("if_fir_fft_r32.o", "fir_fft_kernel"), ("if_fir_fft_odd.o", "fir_odd_kernel")):
+    for obj, name, count in (("if_fir_fft_r4.o", "fir_fft_kernel", 36), ("if_fir_fft_r32.o", "fir_fft_kernel", 52), ("if_fir_fft_d2_r4.o", "fir_fft_kernel", 8),
+                             ("if_fir_fft_d2_r32.o", "fir_fft_kernel", 16), ("if_fir_fft_odd.o", "fir_odd_kernel", 16)):
         assert os.path.exists(os.path.join(csrc, obj)), "build() first: %s" % obj
         forms = {k: v for k, v in read_forms(obj).items() if name in k}
-        assert len(forms) >= 16, (obj, len(forms))
+        assert len(forms) == count, (obj, len(forms))
         for k, v in forms.items():
-            assert "paired" not in k, k
             assert set(v) == {"ds_read_b64"} and v["ds_read_b64"] >= 200, (obj, k[:90], dict(v))
-    forms = read_forms("if_fir_fft_d2_r4.o")
-    assert len(forms) == 8 and all("fir_fft_kernel_paired" in k for k in forms), list(forms)[:2]
-    for k, v in forms.items():
-        assert v["ds_read2_b64"] + v["ds_read2st64_b64"] >= 100, (k[:90], dict(v))
 
 
 def test_bench_line_contract_on_the_committed_run():

@@ -1,9 +1,9 @@
 #!/bin/bash
 # build_ab.sh <name> <extra hipcc flags...> — alternative build of libif_fir.so with other flags for if_fir_fft.hip
 # (a DEVELOPMENT build: it replaces libif_fir_dev.so, which the tools load; A/B timing through tools/sweep_libs.sh; development tool).  Output: qo-100-tools_amd/libif_fir_ab_<name>.so
-# The units are those of csrc/Makefile: host side, one per overlap length (IR load-store vectorizer off: NOPAIR), one per overlap length for the
-# decimate-by-2 tails (-DIF_FIR_FFT_DEC2_UNIT, vectorizer on), the odd-decimation kernel.  NOPAIR= in the environment builds the main units with the
-# vectorizer on.  D2FLAGS="..." adds flags to the decimate-by-2 units only; REUSE_MAIN=1 links the other units' objects of the regular build
+# The units are those of csrc/Makefile: host side, one per overlap length, one per overlap length for the decimate-by-2 tails
+# (-DIF_FIR_FFT_DEC2_UNIT), the odd-decimation kernel; the device units with the IR load-store vectorizer off (NOPAIR; NOPAIR= in the environment
+# builds them with the vectorizer on).  D2FLAGS="..." adds flags to the decimate-by-2 units only; REUSE_MAIN=1 links the other units' objects of the regular build
 # (csrc/*.o) and compiles the decimate-by-2 units only.
 set -e
 cd "$(dirname "$0")/../qo-100-tools_amd/csrc"
@@ -26,7 +26,7 @@ else
   wait
 fi
 for r in 4 8 16 32 48; do
-  /opt/rocm/bin/hipcc "$@" $FLAGS $D2FLAGS -DIF_FIR_FFT_ROWS=$r -DIF_FIR_FFT_DEC2_UNIT=1 -c if_fir_fft.hip -o /tmp/if_fir_fft_ab_${NAME}_d2_r$r.o &
+  /opt/rocm/bin/hipcc "$@" $FLAGS $NOPAIR $D2FLAGS -DIF_FIR_FFT_ROWS=$r -DIF_FIR_FFT_DEC2_UNIT=1 -c if_fir_fft.hip -o /tmp/if_fir_fft_ab_${NAME}_d2_r$r.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libif_fir_ab_$NAME.so if_fir_kernels.o $HOSTO $OBJS $ODDO \
