@@ -585,7 +585,6 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 #ifndef IF_FIR_FFT_DEC2_PFI
 #define IF_FIR_FFT_DEC2_PFI 1 // (bit 1 spills)
 #endif
-__device__ __forceinline__ constexpr int dec2_order(int j) { return j; }
 #ifndef IF_FIR_FFT_EARLY_GROUPS
 #define IF_FIR_FFT_EARLY_GROUPS 4
 #endif
