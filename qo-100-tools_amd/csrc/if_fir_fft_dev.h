@@ -585,6 +585,9 @@ __device__ __forceinline__ srd_t make_srd(const void *p, int64_t bytes)
 #ifndef IF_FIR_FFT_DEC2_PFI
 #define IF_FIR_FFT_DEC2_PFI 1 // (bit 1 spills)
 #endif
+#ifndef IF_FIR_ODD_YREG
+#define IF_FIR_ODD_YREG 2240 // odd-decimation kernel: region stride of the forward transforms' Y^-1 (if_fir_fft_odd.inc)
+#endif
 #ifndef IF_FIR_FFT_EARLY_GROUPS
 #define IF_FIR_FFT_EARLY_GROUPS 4
 #endif
