@@ -44,6 +44,8 @@ WORKLOADS = {
     "fir255_dec3_2p28": (255, 3, 28, "255-tap FIR, decimate-by-3 (round 4: blocks of 3 x 1024 samples, three forward 1024-point transforms + one inverse), 2^28 samples"),
     "fir255_dec9_2p28": (255, 9, 28, "255-tap FIR, decimate-by-9 (the decimate-by-3 kernel keeping every 3rd output), 2^28 samples"),
     "fir511_dec3_2p28": (511, 3, 28, "511-tap FIR, decimate-by-3 (4 of 16 output rows of a block dropped), 2^28 samples"),
+    "fir255_dec6_2p28": (255, 6, 28, "255-tap FIR, decimate-by-6 (the decimate-by-2 tail keeping every third output), 2^28 samples"),
+    "fir255_dec12_2p28": (255, 12, 28, "255-tap FIR, decimate-by-12 (the decimate-by-4 tail keeping every third output), 2^28 samples"),
     "fir255_dec5_2p28": (255, 5, 28, "255-tap FIR, decimate-by-5 (full-rate pipeline + selecting store: no decimating tail for 5, 7, 11, ...), 2^28 samples"),
     "fir255_dec7_2p28": (255, 7, 28, "255-tap FIR, decimate-by-7 (selecting store), 2^28 samples"),
     "fir255_dec25_2p28": (255, 25, 28, "255-tap FIR, decimate-by-25 (selecting store), 2^28 samples"),

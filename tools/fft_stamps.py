@@ -27,9 +27,15 @@ with fir.IfFir(fir.bpf_design(taps_n), decim, 0, dev=True, lib_path=lib_path) as
     torch.cuda.synchronize()
     f.synth_device(x.data_ptr(), 0, n, 0)
     f.synchronize()
+    src = x
+    if "_i16_" in wl:   # int16 input front-end: the same stream as int16 pairs
+        src = (x * 32767.0).round().clamp(-32768, 32767).to(torch.int16)
+        f.set_input_format(fir.INPUT_I16)
+    if "_nco_" in wl:
+        f.set_nco(1638.0 / 8192.0)
     f.debug_stamps()
     for _ in range(3):
-        f.process_device(x.data_ptr(), y.data_ptr(), n)
+        f.process_device(src.data_ptr(), y.data_ptr(), n)
     f.synchronize()
     raw = f.debug_stamps(2048).astype(np.int64).reshape(-1)
     s = raw[:8 * 32 * 8].reshape(8, 32, 8)
