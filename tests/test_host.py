@@ -687,6 +687,17 @@ def test_keep_every_index_arithmetic_of_the_decimating_tail():
                     q2 = t // sub
                     q, rem = bq * lout + q2, t - q2 * sub
                 assert (q, rem) == divmod(blk * lout, sub), (sub, lout, blk)
+        # round 5 (KeepEvery::store_offset): both factors of both products fit 24 bits (v_mul_u32_u24, full rate), and the byte offset from the
+        # block's first kept output, (index - qb) * 8 with qb = q + (rem ? 1 : 0), is (qd - (rem ? 1 : 0)) * 8 in 32-bit arithmetic -- never negative
+        assert int(u.max()) < 2 ** 24 and magic < 2 ** 24 and sub < 2 ** 24
+        for rem in range(sub):
+            qd = (u + np.uint64(rem)) // np.uint64(sub)
+            kept = (u + np.uint64(rem)) % np.uint64(sub) == 0
+            q = 12345678901                                      # any block quotient: it cancels
+            index = q + qd[kept].astype(np.int64)
+            qb = q + (1 if rem else 0)
+            off32 = (qd[kept].astype(np.int64) - (1 if rem else 0)) * 8
+            assert np.array_equal((index - qb) * 8, off32) and (off32 >= 0).all() and int(off32.max()) < 2 ** 32, (sub, rem)
 
 
 def test_filter_bank_decimation_8_routing(fir):
