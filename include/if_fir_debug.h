@@ -17,6 +17,8 @@
  *                  to tolerance; A/B timing and tests); 8192 (round 4) both slot parities of such a call as two launches instead of one
  *                  16384 (round 5) every wave of a workgroup requests its first block ahead of the table copy (the form up to round 5; since
  *                  then only the first wave of every SIMD does: same results, A/B timing)
+ *                  262144 (round 5) no single-round launches: a call of at most one block per wave of the chip fills eight waves per workgroup
+ *                  as before instead of one block per wave dealt over all CUs (same results, A/B timing; 131072 is the launcher's own bit)
  *   3000           decimation 2, 6, 10, ..., 62 through the full-rate kernel + selecting store instead of the decimate-by-2 tail (same results to
  *                  tolerance; A/B timing)
  *   4000           the next call fails before anything is launched (IF_FIR_DEBUG=1): lets tests reach callers' error paths
