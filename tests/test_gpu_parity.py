@@ -297,6 +297,40 @@ def test_fft_backend_run_queue_on_small_grid(fir, oracle, t, d, i16):
         assert f.debug_queue_faults() == 0      # no bounded wait of the block queue expired
 
 
+@pytest.mark.parametrize("t,d,i16", [(255, 4, False), (127, 1, False), (255, 8, True), (255, 2, False), (255, 5, False)])
+def test_fft_backend_single_round_launches(fir, oracle, t, d, i16, monkeypatch):
+    """Round 5: a call of at most one block per wave of the chip is a single-round launch -- one block per wave, dealt slot-major over all CUs, no block
+    queue.  Which wave of which workgroup computes a block must not matter: calls of 1 ... 300 blocks (and one just beyond the single-round limit of a 2-workgroup grid)
+    against the same calls with single-round launches switched off (development tuning 1000000 + 262144), bit for bit, and against the oracle."""
+    monkeypatch.setenv("IF_FIR_DEBUG", "1")
+    taps = fir.bpf_design(t)
+    rng = np.random.default_rng(91)
+    for n in (1, 257, 3_900, 19_000, 65_536, 1_150_000):
+        if i16:
+            xi = rng.integers(-32768, 32768, 2 * n, dtype=np.int16)
+            x = xi.astype(np.float32) * np.float32(2.0 ** -15)
+        else:
+            x = oracle.synth_iq(n, 23 + n % 7)
+        src = xi if i16 else x
+        ref = oracle.fir_f64(taps, x, d)
+        with fir.IfFir(taps, d, n, dev=True) as f:
+            if i16:
+                f.set_input_format(fir.INPUT_I16)
+            f.set_backend(fir.BACKEND_HIP_FFT)
+            y0 = f.process(src)
+            if n >= 3000:    # (shorter calls end inside the filter's rise: the error metric is relative to the largest output)
+                l2, mx = oracle.err_metrics(y0, ref)
+                assert l2 <= TOL and mx <= TOL, (n, l2, mx)
+            else:
+                assert np.allclose(y0, ref, rtol=0.0, atol=2e-6), n
+            for tuning in (1262144, 2002):          # single-round launches off; a 2-workgroup grid (single round up to 16 blocks, the queue beyond)
+                f.reset()
+                f.set_tuning(tuning)
+                y1 = f.process(src)
+                assert np.array_equal(y1, y0), (n, tuning, int(np.argmax(y1 != y0)) if len(y0) else -1)
+            assert f.debug_queue_faults() == 0
+
+
 def test_diagnostic_variants_need_the_debug_switch(fir, gpu_ok):
     """The product library takes schedule variants 0..6 only; the development library (include/if_fir_debug.h) has the
     grid limits and, with IF_FIR_DEBUG=1, the diagnostic launches that skip loads or stores (wrong results)."""
